@@ -1,0 +1,185 @@
+/*
+ * moonrt.h -- C ABI of libmoonrt.so, the MI355X (gfx950) renderer that replaces the
+ * PlotOptiX/OptiX backend behind MoonRTX's `self.rt` object.
+ *
+ * The reference has no C FFI: its renderer boundary is the Python object created at
+ * moonrtx/moon_renderer.py:571-575 (`TkOptiX(width, height, on_launch_finished=...)`).
+ * Every entry point below cites the reference call(s) on that object which it serves; the
+ * Python facade `moonrtx_amd/tkoptix.py` maps those calls 1:1 onto this ABI through ctypes.
+ *
+ * Conventions
+ *   - plain C types only; host pointers are borrowed for the duration of the call;
+ *   - every function returns 0 on success or a negative MRTX_E_* code; the text of the last
+ *     failure on a context is available from mrtx_last_error();
+ *   - no C++ exception crosses the ABI and nothing aborts the process;
+ *   - one context is driven by one thread at a time (the facade's render thread holds the
+ *     `_padlock` while it calls in, moon_renderer.py:849-852).
+ */
+#ifndef MOONRT_H
+#define MOONRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRTX_ABI_VERSION 1
+
+enum {
+    MRTX_OK = 0,
+    MRTX_E_INVALID = -1,   /* bad argument                                   */
+    MRTX_E_DEVICE = -2,    /* a HIP call failed (text in mrtx_last_error)    */
+    MRTX_E_STATE = -3,     /* call made in the wrong state (e.g. no DEM yet) */
+    MRTX_E_NOMEM = -4
+};
+
+typedef struct mrtx_ctx mrtx_ctx;
+
+/* Frame + sharding description.  rank/world shard the image in tiles of tile_w x tile_h
+ * pixels: tile t (raster order) belongs to rank (t % world).  world == 1 renders everything. */
+typedef struct MrtxConfig {
+    int32_t device;          /* HIP device ordinal                                             */
+    int32_t width, height;   /* TkOptiX(width=, height=)            moon_renderer.py:571-573   */
+    int32_t rank, world;     /* image-tile sharding (new; the reference is single-GPU)        */
+    int32_t tile_w, tile_h;  /* sharding tile, 0 = default 32 x 32                              */
+} MrtxConfig;
+
+/* String-keyed knobs of the reference collapsed into one POD.
+ *   set_float("scene_epsilon" | "marching_step" | "marching_step_eps")  moon_renderer.py:586-588
+ *   set_float("tonemap_exposure" | "tonemap_gamma")                      moon_renderer.py:598-599, :367
+ *   set_uint("path_seg_range", 2, 4)                                      moon_renderer.py:583
+ *   set_param(min_accumulation_step=, max_accumulation_frames=)           moon_renderer.py:578, :475, :487 */
+typedef struct MrtxParams {
+    float scene_epsilon;
+    float marching_step;
+    float marching_step_eps;
+    float tonemap_exposure;
+    float tonemap_gamma;
+    uint32_t path_seg_min, path_seg_max;
+    uint32_t spp_per_launch;   /* samples per pixel per accumulation block: 1,2,4,...,64 */
+    uint32_t max_spp;          /* max_accumulation_frames (informational for the ABI)   */
+    uint32_t seed;
+    float const_albedo[3];     /* reflectance used when no colour texture is bound       */
+    uint32_t flags;            /* MRTX_F_*                                                */
+} MrtxParams;
+
+#define MRTX_F_COUNT_STATS 1u  /* maintain the deterministic sample counters of MrtxStats */
+
+typedef struct MrtxStats {
+    uint64_t primary_rays;        /* camera samples (pixel x spp), the headline "ray"      */
+    uint64_t primary_hits;        /* camera samples that hit the Moon                      */
+    uint64_t shadow_rays;         /* light-sample rays marched                             */
+    uint64_t height_samples;      /* DEM bilinear evaluations (16 B each), all segments    */
+    uint64_t colour_fetches;      /* colour bilinear fetches (16 B each)                   */
+    uint64_t background_fetches;  /* environment texel fetches (4 B each)                  */
+    double kernel_ms;             /* HIP-event time of the render kernel(s) of this call   */
+    uint32_t launches;
+    uint32_t reserved;
+} MrtxStats;
+
+/* TkOptiX(width, height, ...) -- moon_renderer.py:571-575.  Allocates accumulation + hit buffers. */
+int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out);
+/* rt.close() -- moon_renderer.py:880-884 */
+void mrtx_destroy(mrtx_ctx* ctx);
+const char* mrtx_last_error(mrtx_ctx* ctx);
+int mrtx_abi_version(void);
+
+/* rt.set_displacement("moon", elevation, refresh=False) -- moon_renderer.py:624.
+ * `host` is the float32 (h, w) array load_elevation_data returns (data_loader.py:166-247):
+ * equirectangular, row 0 = +90 deg, column 0 = -180 deg, max exactly 1.0. */
+int mrtx_upload_dem(mrtx_ctx* ctx, const float* host, int32_t h, int32_t w);
+/* Same, from a device pointer the caller owns (synthetic / device-built DEMs): the context
+ * keeps the pointer, it does not copy.  Caller keeps it alive until destroy or re-upload. */
+int mrtx_bind_dem_device(mrtx_ctx* ctx, const void* dev_f32, int32_t h, int32_t w);
+
+/* rt.set_texture_2d("moon_color", rgba_u8) + update_material("diffuse", {"ColorTextures": [...]})
+ * -- moon_renderer.py:613-617.  NULL => const_albedo of MrtxParams. */
+int mrtx_upload_color(mrtx_ctx* ctx, const uint8_t* rgba, int32_t h, int32_t w);
+int mrtx_bind_color_device(mrtx_ctx* ctx, const void* dev_rgba8, int32_t h, int32_t w);
+
+/* rt.set_background_mode("TextureEnvironment"); rt.set_background(star_map, gamma=, rt_format="UByte4")
+ * -- moon_renderer.py:604-609.  NULL => black (`set_background(0)`). Texels are RGBA8, already in the
+ * renderer's linear space (the facade applies the gamma of set_background on the host). */
+int mrtx_upload_background(mrtx_ctx* ctx, const uint8_t* rgba, int32_t h, int32_t w);
+
+/* set_float / set_uint / set_param / set_ambient / add_postproc -- moon_renderer.py:578-600 */
+int mrtx_set_params(mrtx_ctx* ctx, const MrtxParams* p);
+void mrtx_default_params(MrtxParams* p);
+
+/* setup_camera / update_camera / _optix.set_camera_fov -- moon_renderer.py:627-635,
+ * renderer_navigation.py:73,150,224,521.  Pinhole; vfov is the vertical field of view, degrees. */
+int mrtx_set_camera(mrtx_ctx* ctx, const double eye[3], const double target[3], const double up[3],
+                    double vfov_deg);
+
+/* set_data("moon", geom="ParticleSetTextured", geom_attr="DisplacedSurface", pos, u, v, r) and
+ * update_data("moon", u=, v=) -- moon_renderer.py:620-621, :854.  u = north pole, v = direction of
+ * longitude 0 (renderer_navigation.py:47-53, :486-490), both in scene coordinates. */
+int mrtx_set_moon_frame(mrtx_ctx* ctx, const double center[3], double radius, const double u[3],
+                        const double v[3]);
+
+/* setup_light("sun", color=, radius=, in_geometry=False) / update_light(pos=, color=, radius=)
+ * -- moon_renderer.py:640-641, :347, :859-860.  `radiance` is the light colour (scalar, white). */
+int mrtx_set_light(mrtx_ctx* ctx, const double pos[3], double radius, double radiance);
+
+/* set_data("sun_disk", geom="ParticleSet", mat="flat", pos, r, c=2.0) / update_data(...)
+ * -- moon_renderer.py:647-650, :855.  radius <= 0 disables the disk. */
+int mrtx_set_sun_disk(mrtx_ctx* ctx, const double pos[3], double radius, double radiance);
+
+/* rt.refresh_scene() -- moon_renderer.py:488, :871: restart the accumulation cycle. */
+int mrtx_reset_accum(mrtx_ctx* ctx);
+
+/* One or more accumulation blocks (what the PlotOptiX render thread does between two
+ * on_launch_finished callbacks, moon_renderer.py:574; renderer_status.py:239).  Each block adds
+ * spp_per_launch samples to every pixel this rank owns.  Blocking.  `out` may be NULL. */
+int mrtx_render(mrtx_ctx* ctx, int32_t n_blocks, MrtxStats* out);
+
+/* Read-back.  All are full-frame W*H arrays, caller-allocated; on a sharded context pixels of
+ * other ranks read as zero.
+ *   linear : float32 RGBA, mean linear radiance, A = 1 where any sample hit geometry
+ *   rgba8  : the "Gamma" post-process (exposure * L)^(1/gamma) -> 8 bit, moon_renderer.py:598-600
+ *   hits   : float32 (x, y, z, d) in scene coordinates, d <= 0 == miss -- rt._get_hit_at(x, y),
+ *            moon_renderer.py:1138, renderer_navigation.py:195-203 */
+int mrtx_read_linear(mrtx_ctx* ctx, float* rgba_out);
+int mrtx_read_rgba8(mrtx_ctx* ctx, uint8_t* out);
+int mrtx_read_hits(mrtx_ctx* ctx, float* xyzd_out);
+int mrtx_samples_done(mrtx_ctx* ctx, uint32_t* out);
+
+/* ---- multi-GPU exchange step (new: the reference is single-GPU) -------------------------------
+ * A rank packs the tiles it owns (linear float4 radiance followed by float4 hits) into a compact
+ * device buffer the caller provides (e.g. a torch tensor handed to an RCCL gather), and rank 0
+ * scatters the gathered buffers back into frame order. */
+int mrtx_shard_bytes(mrtx_ctx* ctx, int32_t rank, uint64_t* out);   /* size of rank's packed buffer */
+int mrtx_pack_shard(mrtx_ctx* ctx, void* dev_dst, void* hip_stream);
+int mrtx_unpack_shard(mrtx_ctx* ctx, int32_t src_rank, const void* dev_src, void* hip_stream);
+
+/* Raw device pointers of the context's buffers (for zero-copy wrapping by the host side). */
+enum { MRTX_BUF_ACCUM = 0, MRTX_BUF_HITS = 1, MRTX_BUF_DEM = 2, MRTX_BUF_COLOR = 3 };
+int mrtx_device_ptr(mrtx_ctx* ctx, int32_t which, void** out, uint64_t* bytes);
+
+/* ---- ingest kernels (data_loader.py:166-247, the step before set_displacement) ----------------
+ * Device-side restatement of load_elevation_data: int16 LDEM units -> block mean (two-stage f32,
+ * axis 4 then axis 2) -> * 0.5/1737400 -> + 1 -> / max.  src_dev is (h*d, w*d) int16 on the device,
+ * dst_dev is (h, w) float32 on the device.  radius_scale receives the pre-normalisation maximum. */
+int mrtx_dem_from_ldem(int32_t device, const void* src_dev_i16, int32_t h, int32_t w, int32_t downscale,
+                       void* dst_dev_f32, float* radius_scale, char* err, int32_t err_len);
+/* Seeded synthetic LDEM-like int16 source written straight into device memory (bench input). */
+int mrtx_synth_ldem(int32_t device, void* dst_dev_i16, int32_t h, int32_t w, uint32_t seed,
+                    char* err, int32_t err_len);
+/* Seeded synthetic RGBA8 albedo texture (already through the 0.2+0.75v LUT range), device memory. */
+int mrtx_synth_color(int32_t device, void* dst_dev_rgba8, int32_t h, int32_t w, uint32_t seed,
+                     char* err, int32_t err_len);
+/* Plain device allocation helpers so the host side needs no other GPU runtime for inputs. */
+int mrtx_dev_alloc(int32_t device, uint64_t bytes, void** out);
+int mrtx_dev_free(int32_t device, void* p);
+int mrtx_dev_download(int32_t device, void* host_dst, const void* dev_src, uint64_t bytes);
+int mrtx_dev_upload(int32_t device, void* dev_dst, const void* host_src, uint64_t bytes);
+
+/* Math conformance probe: evaluates the renderer's own atan2 / bilinear-address primitives on the
+ * device for n inputs (tests compare them with the oracle bit for bit). */
+int mrtx_probe_atan2(int32_t device, const float* y, const float* x, float* out, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOONRT_H */

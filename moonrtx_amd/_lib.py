@@ -1,0 +1,114 @@
+"""ctypes loader for libmoonrt.so (the C ABI of include/moonrt.h).
+
+The library is built in-tree by `moonrtx_amd.build.build_native()` / `make -C moonrtx_amd/csrc`.
+There is NO CPU fallback: if the shared object is missing or a symbol is absent this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmoonrt.so")
+
+ABI_VERSION = 1
+
+
+class MrtxConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32)]
+
+
+class MrtxParams(C.Structure):
+    _fields_ = [("scene_epsilon", C.c_float), ("marching_step", C.c_float), ("marching_step_eps", C.c_float),
+                ("tonemap_exposure", C.c_float), ("tonemap_gamma", C.c_float),
+                ("path_seg_min", C.c_uint32), ("path_seg_max", C.c_uint32),
+                ("spp_per_launch", C.c_uint32), ("max_spp", C.c_uint32), ("seed", C.c_uint32),
+                ("const_albedo", C.c_float * 3), ("flags", C.c_uint32)]
+
+
+class MrtxStats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("primary_hits", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("height_samples", C.c_uint64), ("colour_fetches", C.c_uint64),
+                ("background_fetches", C.c_uint64), ("kernel_ms", C.c_double),
+                ("launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+F_COUNT_STATS = 1
+BUF_ACCUM, BUF_HITS, BUF_DEM, BUF_COLOR = 0, 1, 2, 3
+
+_D3 = C.POINTER(C.c_double)
+_VP = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/moonrt.h declares
+SIGNATURES = {
+    "mrtx_abi_version": (C.c_int, []),
+    "mrtx_create": (C.c_int, [C.POINTER(MrtxConfig), C.POINTER(_VP)]),
+    "mrtx_destroy": (None, [_VP]),
+    "mrtx_last_error": (C.c_char_p, [_VP]),
+    "mrtx_upload_dem": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
+    "mrtx_bind_dem_device": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
+    "mrtx_upload_color": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
+    "mrtx_bind_color_device": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
+    "mrtx_upload_background": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
+    "mrtx_set_params": (C.c_int, [_VP, C.POINTER(MrtxParams)]),
+    "mrtx_default_params": (None, [C.POINTER(MrtxParams)]),
+    "mrtx_set_camera": (C.c_int, [_VP, _D3, _D3, _D3, C.c_double]),
+    "mrtx_set_moon_frame": (C.c_int, [_VP, _D3, C.c_double, _D3, _D3]),
+    "mrtx_set_light": (C.c_int, [_VP, _D3, C.c_double, C.c_double]),
+    "mrtx_set_sun_disk": (C.c_int, [_VP, _D3, C.c_double, C.c_double]),
+    "mrtx_reset_accum": (C.c_int, [_VP]),
+    "mrtx_render": (C.c_int, [_VP, C.c_int32, C.POINTER(MrtxStats)]),
+    "mrtx_read_linear": (C.c_int, [_VP, _VP]),
+    "mrtx_read_rgba8": (C.c_int, [_VP, _VP]),
+    "mrtx_read_hits": (C.c_int, [_VP, _VP]),
+    "mrtx_samples_done": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
+    "mrtx_shard_bytes": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64)]),
+    "mrtx_pack_shard": (C.c_int, [_VP, _VP, _VP]),
+    "mrtx_unpack_shard": (C.c_int, [_VP, C.c_int32, _VP, _VP]),
+    "mrtx_device_ptr": (C.c_int, [_VP, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
+    "mrtx_dem_from_ldem": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32, _VP,
+                                     C.POINTER(C.c_float), C.c_char_p, C.c_int32]),
+    "mrtx_synth_ldem": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32, C.c_uint32, C.c_char_p, C.c_int32]),
+    "mrtx_synth_color": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32, C.c_uint32, C.c_char_p, C.c_int32]),
+    "mrtx_dev_alloc": (C.c_int, [C.c_int32, C.c_uint64, C.POINTER(_VP)]),
+    "mrtx_dev_free": (C.c_int, [C.c_int32, _VP]),
+    "mrtx_dev_download": (C.c_int, [C.c_int32, _VP, _VP, C.c_uint64]),
+    "mrtx_dev_upload": (C.c_int, [C.c_int32, _VP, _VP, C.c_uint64]),
+    "mrtx_probe_atan2": (C.c_int, [C.c_int32, _VP, _VP, _VP, C.c_int32]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Return the loaded library; raise NativeLibraryError if it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C moonrtx_amd/csrc` (needs hipcc). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mrtx_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library {lib.mrtx_abi_version()}, host {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def vec3(v):
+    a = (C.c_double * 3)(float(v[0]), float(v[1]), float(v[2]))
+    return a

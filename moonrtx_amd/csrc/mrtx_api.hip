@@ -1,0 +1,547 @@
+// mrtx_api.hip -- host side of libmoonrt.so: the C ABI declared in include/moonrt.h.
+//
+// The context keeps the scene the way the reference describes it to its renderer object (float64
+// camera / moon frame / light / Sun disk, moon_renderer.py:570-650 and :824-871) and derives the
+// float32 per-launch constant block (FrameC) from it right before every launch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/moonrt.h"
+#include "mrtx_device.h"
+
+hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, hipStream_t st);
+hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t npix, uint32_t ns, hipStream_t st);
+hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
+                                     float invg, hipStream_t st);
+hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
+                            int tiles_x, int n_tiles, int rank, int world, int slots, hipStream_t st);
+hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
+                              int tiles_x, int n_tiles, int src_rank, int world, int slots, hipStream_t st);
+hipError_t mrtx_launch_ldem(const int16_t* src, float* dst, int h, int w, int d, unsigned int* max_bits,
+                            hipStream_t st);
+hipError_t mrtx_launch_synth_ldem(int16_t* dst, int h, int w, uint32_t seed, hipStream_t st);
+hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, hipStream_t st);
+hipError_t mrtx_launch_probe_atan2(const float* y, const float* x, float* out, int n, hipStream_t st);
+
+struct mrtx_ctx {
+    MrtxConfig cfg{};
+    MrtxParams prm{};
+    int tiles_x = 0, tiles_y = 0, n_tiles = 0, n_local = 0, slots = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float* accum = nullptr;
+    float* hits = nullptr;
+    void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
+    float* dem = nullptr; bool dem_owned = false; int dem_h = 0, dem_w = 0;
+    uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
+    uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
+    unsigned long long* stats_dev = nullptr;
+    uint32_t blocks_done = 0;
+    double eye[3] = {0, -300, 0}, target[3] = {0, 0, 0}, up[3] = {0, 0, 1}, vfov = 4.2421875;
+    double center[3] = {0, 0, 0}, radius = 10.0, u[3] = {0, 0, 1}, v[3] = {0, -1, 0};
+    double light_pos[3] = {0, -21460, 0}, light_radius = 100.0, light_radiance = 0.0;
+    double sun_pos[3] = {0, 3100, 0}, sun_radius = 0.0, sun_radiance = 2.0;
+    std::string err;
+};
+
+namespace {
+
+int fail(mrtx_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), MRTX_E_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+const double kPiD = 3.14159265358979323846;
+
+void unit3(double v[3]) {
+    const double l = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    v[0] /= l; v[1] /= l; v[2] /= l;
+}
+void cross(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+uint32_t mix32h(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+void set_grid(GridC& g, int h, int w) {
+    g.h = h; g.w = w;
+    g.row_scale = (float)(-(double)h / kPiD);
+    g.row_off = (float)(0.5 * (double)h - 0.5);
+    g.col_scale = (float)((double)w / (2.0 * kPiD));
+    g.col_off = (float)(0.5 * (double)w - 0.5);
+    g.wf = (float)w;
+}
+
+// Scene (float64) -> per-launch constants.  DESIGN.md section 3.1 lists every formula; the oracle
+// derives the same block on its own and tests compare the two float for float.
+void build_frame(const mrtx_ctx* c, FrameC& f) {
+    std::memset(&f, 0, sizeof f);
+    f.W = c->cfg.width; f.H = c->cfg.height;
+    double wv[3], uv[3], vv[3];
+    for (int i = 0; i < 3; i++) wv[i] = c->target[i] - c->eye[i];
+    unit3(wv);
+    cross(wv, c->up, uv); unit3(uv);
+    cross(uv, wv, vv);
+    const double th = std::tan(c->vfov * kPiD / 360.0);
+    const double aspect = (double)f.W / (double)f.H;
+    for (int i = 0; i < 3; i++) {
+        f.Wd[i] = (float)wv[i];
+        f.Ux[i] = (float)(uv[i] * (th * aspect));
+        f.Vy[i] = (float)(vv[i] * th);
+        f.oc[i] = c->eye[i] - c->center[i];
+        f.centerf[i] = (float)c->center[i];
+        f.eyef[i] = (float)c->eye[i];
+    }
+    f.two_over_w = (float)(2.0 / (double)f.W);
+    f.two_over_h = (float)(2.0 / (double)f.H);
+    f.cq = ((f.oc[0] * f.oc[0] + f.oc[1] * f.oc[1]) + f.oc[2] * f.oc[2]) - c->radius * c->radius;
+    // moon frame rows: east-90, lon-0, north.  u = north pole, v = longitude-0 direction
+    // (moon_renderer.py:621, :844-845; renderer_navigation.py:47-53)
+    double ez[3] = {c->u[0], c->u[1], c->u[2]}, v0[3], ex[3];
+    unit3(ez);
+    const double dp = (c->v[0] * ez[0] + c->v[1] * ez[1]) + c->v[2] * ez[2];
+    for (int i = 0; i < 3; i++) v0[i] = c->v[i] - dp * ez[i];
+    unit3(v0);
+    cross(ez, v0, ex);
+    for (int j = 0; j < 3; j++) { f.M[0][j] = ex[j]; f.M[1][j] = v0[j]; f.M[2][j] = ez[j]; }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) f.Mf[i][j] = (float)f.M[i][j];
+    f.Rf = (float)c->radius;
+    f.R2f = f.Rf * f.Rf;
+    double lr[3];
+    for (int i = 0; i < 3; i++) lr[i] = c->light_pos[i] - c->center[i];
+    for (int i = 0; i < 3; i++) f.Lb[i] = (float)((f.M[i][0] * lr[0] + f.M[i][1] * lr[1]) + f.M[i][2] * lr[2]);
+    f.rL2 = (float)(c->light_radius * c->light_radius);
+    f.rad2 = (float)(2.0 * c->light_radiance);
+    f.sun_on = c->sun_radius > 0.0 ? 1 : 0;
+    double sr[3];
+    for (int i = 0; i < 3; i++) { sr[i] = c->sun_pos[i] - c->eye[i]; f.sc[i] = (float)sr[i]; }
+    f.sun_cq = (float)(((sr[0] * sr[0] + sr[1] * sr[1]) + sr[2] * sr[2]) - c->sun_radius * c->sun_radius);
+    f.sun_rad = (float)c->sun_radiance;
+    f.step = c->prm.marching_step;
+    f.eps = c->prm.marching_step_eps;
+    f.scene_eps = c->prm.scene_epsilon;
+    f.nbis = 0;
+    for (double wdt = (double)f.step; wdt > (double)f.eps && f.nbis < 24; wdt *= 0.5) f.nbis++;
+    f.kmax = (int)(2.0 * c->radius / (double)f.step) + 8;
+    set_grid(f.gd, c->dem_h, c->dem_w);
+    f.dlat_scale = (float)((double)c->dem_h / (2.0 * kPiD));
+    f.dlon_scale = (float)((double)c->dem_w / (4.0 * kPiD));
+    if (c->color) set_grid(f.gc, c->color_h, c->color_w);
+    if (c->bg) {
+        f.bg_h = c->bg_h; f.bg_w = c->bg_w;
+        f.bg_row_scale = (float)(-(double)c->bg_h / kPiD);
+        f.bg_row_off = (float)(0.5 * (double)c->bg_h);
+        f.bg_col_scale = (float)((double)c->bg_w / (2.0 * kPiD));
+        f.bg_col_off = (float)(0.5 * (double)c->bg_w);
+    }
+    f.key0 = mix32h(c->prm.seed ^ 0x9E3779B9u);
+    for (int i = 0; i < 3; i++) f.const_albedo[i] = c->prm.const_albedo[i];
+    f.dem = c->dem; f.color = c->color; f.bg = c->bg;
+    f.tile_w = c->cfg.tile_w; f.tile_h = c->cfg.tile_h;
+    f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y;
+    f.rank = c->cfg.rank; f.world = c->cfg.world; f.n_local_tiles = c->n_local;
+    f.accum = c->accum; f.hits = c->hits; f.stats = c->stats_dev;
+}
+
+int check_vec(const double* p) {
+    if (!p) return 0;
+    for (int i = 0; i < 3; i++)
+        if (!std::isfinite(p[i])) return 0;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrtx_abi_version(void) { return MRTX_ABI_VERSION; }
+
+void mrtx_default_params(MrtxParams* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->scene_epsilon = 1.0e-4f;      // moon_renderer.py:99
+    p->marching_step = 5.0e-3f;      // :100
+    p->marching_step_eps = 3.0e-4f;  // :101
+    p->tonemap_exposure = 0.9f;      // :598
+    p->tonemap_gamma = 2.2f;
+    p->path_seg_min = 2; p->path_seg_max = 4;  // :583
+    p->spp_per_launch = 64; p->max_spp = 64;   // :130
+    p->seed = 1;
+    p->const_albedo[0] = p->const_albedo[1] = p->const_albedo[2] = 75.0f / 255.0f;  // lut[128], gamma 2.2
+    p->flags = MRTX_F_COUNT_STATS;
+}
+
+int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
+    if (!cfg || !out) return MRTX_E_INVALID;
+    *out = nullptr;
+    if (cfg->width < 1 || cfg->height < 1 || cfg->width > 32768 || cfg->height > 32768) return MRTX_E_INVALID;
+    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return MRTX_E_INVALID;
+    mrtx_ctx* c = new (std::nothrow) mrtx_ctx();
+    if (!c) return MRTX_E_NOMEM;
+    c->cfg = *cfg;
+    if (c->cfg.tile_w <= 0) c->cfg.tile_w = 32;
+    if (c->cfg.tile_h <= 0) c->cfg.tile_h = 32;
+    if ((c->cfg.tile_w & 15) || (c->cfg.tile_h & 15)) { delete c; return MRTX_E_INVALID; }
+    mrtx_default_params(&c->prm);
+    c->tiles_x = (cfg->width + c->cfg.tile_w - 1) / c->cfg.tile_w;
+    c->tiles_y = (cfg->height + c->cfg.tile_h - 1) / c->cfg.tile_h;
+    c->n_tiles = c->tiles_x * c->tiles_y;
+    c->slots = (c->n_tiles + cfg->world - 1) / cfg->world;
+    c->n_local = (c->n_tiles - cfg->rank + cfg->world - 1) / cfg->world;
+    *out = c;  // from here on the caller can read mrtx_last_error and must destroy
+    const size_t fb = (size_t)cfg->width * cfg->height * 16;
+    HIPCHK(c, hipSetDevice(cfg->device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreate(&c->ev0));
+    HIPCHK(c, hipEventCreate(&c->ev1));
+    HIPCHK(c, hipMalloc((void**)&c->accum, fb));
+    HIPCHK(c, hipMalloc((void**)&c->hits, fb));
+    HIPCHK(c, hipMalloc(&c->scratch, fb));
+    HIPCHK(c, hipMalloc((void**)&c->stats_dev, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->accum, 0, fb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->hits, 0, fb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MRTX_OK;
+}
+
+void mrtx_destroy(mrtx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->accum) (void)hipFree(c->accum);
+    if (c->hits) (void)hipFree(c->hits);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->stats_dev) (void)hipFree(c->stats_dev);
+    if (c->dem && c->dem_owned) (void)hipFree(c->dem);
+    if (c->color && c->color_owned) (void)hipFree(c->color);
+    if (c->bg) (void)hipFree(c->bg);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* mrtx_last_error(mrtx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int mrtx_upload_dem(mrtx_ctx* c, const float* host, int32_t h, int32_t w) {
+    if (!c) return MRTX_E_INVALID;
+    if (!host || h < 2 || w < 2) return fail(c, MRTX_E_INVALID, "DEM must be a float32 (h>=2, w>=2) array");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->dem && c->dem_owned) { HIPCHK(c, hipFree(c->dem)); }
+    c->dem = nullptr; c->dem_owned = false;
+    const size_t bytes = (size_t)h * w * sizeof(float);
+    HIPCHK(c, hipMalloc((void**)&c->dem, bytes));
+    c->dem_owned = true;
+    HIPCHK(c, hipMemcpy(c->dem, host, bytes, hipMemcpyHostToDevice));
+    c->dem_h = h; c->dem_w = w;
+    return MRTX_OK;
+}
+int mrtx_bind_dem_device(mrtx_ctx* c, const void* dev, int32_t h, int32_t w) {
+    if (!c) return MRTX_E_INVALID;
+    if (!dev || h < 2 || w < 2) return fail(c, MRTX_E_INVALID, "bad device DEM");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->dem && c->dem_owned) { HIPCHK(c, hipFree(c->dem)); }
+    c->dem = (float*)dev; c->dem_owned = false; c->dem_h = h; c->dem_w = w;
+    return MRTX_OK;
+}
+int mrtx_upload_color(mrtx_ctx* c, const uint8_t* rgba, int32_t h, int32_t w) {
+    if (!c) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->color && c->color_owned) { HIPCHK(c, hipFree(c->color)); }
+    c->color = nullptr; c->color_owned = false; c->color_h = c->color_w = 0;
+    if (!rgba) return MRTX_OK;
+    if (h < 2 || w < 2) return fail(c, MRTX_E_INVALID, "colour texture must be (h>=2, w>=2, 4) uint8");
+    const size_t bytes = (size_t)h * w * 4;
+    HIPCHK(c, hipMalloc((void**)&c->color, bytes));
+    c->color_owned = true;
+    HIPCHK(c, hipMemcpy(c->color, rgba, bytes, hipMemcpyHostToDevice));
+    c->color_h = h; c->color_w = w;
+    return MRTX_OK;
+}
+int mrtx_bind_color_device(mrtx_ctx* c, const void* dev, int32_t h, int32_t w) {
+    if (!c) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->color && c->color_owned) { HIPCHK(c, hipFree(c->color)); }
+    c->color = (uint8_t*)dev; c->color_owned = false;
+    c->color_h = dev ? h : 0; c->color_w = dev ? w : 0;
+    if (dev && (h < 2 || w < 2)) { c->color = nullptr; return fail(c, MRTX_E_INVALID, "bad device colour texture"); }
+    return MRTX_OK;
+}
+int mrtx_upload_background(mrtx_ctx* c, const uint8_t* rgba, int32_t h, int32_t w) {
+    if (!c) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->bg) { HIPCHK(c, hipFree(c->bg)); }
+    c->bg = nullptr; c->bg_h = c->bg_w = 0;
+    if (!rgba) return MRTX_OK;
+    if (h < 1 || w < 1) return fail(c, MRTX_E_INVALID, "background must be (h>=1, w>=1, 4) uint8");
+    const size_t bytes = (size_t)h * w * 4;
+    HIPCHK(c, hipMalloc((void**)&c->bg, bytes));
+    HIPCHK(c, hipMemcpy(c->bg, rgba, bytes, hipMemcpyHostToDevice));
+    c->bg_h = h; c->bg_w = w;
+    return MRTX_OK;
+}
+
+int mrtx_set_params(mrtx_ctx* c, const MrtxParams* p) {
+    if (!c || !p) return MRTX_E_INVALID;
+    const uint32_t S = p->spp_per_launch;
+    if (S == 0 || S > 64 || (S & (S - 1))) return fail(c, MRTX_E_INVALID, "spp_per_launch must be 1,2,4,...,64");
+    if (!(p->marching_step > 0.0f) || !(p->marching_step_eps > 0.0f) || !(p->scene_epsilon >= 0.0f))
+        return fail(c, MRTX_E_INVALID, "marching_step, marching_step_eps must be > 0 and scene_epsilon >= 0");
+    if (!(p->tonemap_gamma > 0.0f)) return fail(c, MRTX_E_INVALID, "tonemap_gamma must be > 0");
+    if (S != c->prm.spp_per_launch && c->blocks_done != 0)
+        return fail(c, MRTX_E_STATE, "spp_per_launch cannot change inside an accumulation cycle; reset first");
+    c->prm = *p;
+    return MRTX_OK;
+}
+
+int mrtx_set_camera(mrtx_ctx* c, const double eye[3], const double target[3], const double up[3], double vfov) {
+    if (!c) return MRTX_E_INVALID;
+    if (!check_vec(eye) || !check_vec(target) || !check_vec(up) || !(vfov > 0.0 && vfov < 180.0))
+        return fail(c, MRTX_E_INVALID, "bad camera");
+    double w[3] = {target[0] - eye[0], target[1] - eye[1], target[2] - eye[2]}, x[3];
+    cross(w, up, x);
+    if (!((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2] > 0.0)) return fail(c, MRTX_E_INVALID, "camera up is parallel to the view axis");
+    for (int i = 0; i < 3; i++) { c->eye[i] = eye[i]; c->target[i] = target[i]; c->up[i] = up[i]; }
+    c->vfov = vfov;
+    return MRTX_OK;
+}
+int mrtx_set_moon_frame(mrtx_ctx* c, const double center[3], double radius, const double u[3], const double v[3]) {
+    if (!c) return MRTX_E_INVALID;
+    if (!check_vec(center) || !check_vec(u) || !check_vec(v) || !(radius > 0.0)) return fail(c, MRTX_E_INVALID, "bad moon frame");
+    double x[3];
+    cross(u, v, x);
+    if (!((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2] > 0.0)) return fail(c, MRTX_E_INVALID, "moon u and v are parallel");
+    for (int i = 0; i < 3; i++) { c->center[i] = center[i]; c->u[i] = u[i]; c->v[i] = v[i]; }
+    c->radius = radius;
+    return MRTX_OK;
+}
+int mrtx_set_light(mrtx_ctx* c, const double pos[3], double radius, double radiance) {
+    if (!c) return MRTX_E_INVALID;
+    if (!check_vec(pos) || !(radius >= 0.0) || !(radiance >= 0.0)) return fail(c, MRTX_E_INVALID, "bad light");
+    for (int i = 0; i < 3; i++) c->light_pos[i] = pos[i];
+    c->light_radius = radius; c->light_radiance = radiance;
+    return MRTX_OK;
+}
+int mrtx_set_sun_disk(mrtx_ctx* c, const double pos[3], double radius, double radiance) {
+    if (!c) return MRTX_E_INVALID;
+    if (!check_vec(pos) || !std::isfinite(radius) || !(radiance >= 0.0)) return fail(c, MRTX_E_INVALID, "bad sun disk");
+    for (int i = 0; i < 3; i++) c->sun_pos[i] = pos[i];
+    c->sun_radius = radius; c->sun_radiance = radiance;
+    return MRTX_OK;
+}
+
+int mrtx_reset_accum(mrtx_ctx* c) {
+    if (!c) return MRTX_E_INVALID;
+    c->blocks_done = 0;
+    return MRTX_OK;
+}
+
+int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
+    if (!c) return MRTX_E_INVALID;
+    if (n_blocks < 1) return fail(c, MRTX_E_INVALID, "n_blocks must be >= 1");
+    if (!c->dem) return fail(c, MRTX_E_STATE, "no displacement map: call mrtx_upload_dem first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    FrameC f;
+    build_frame(c, f);
+    f.first_block = c->blocks_done;
+    f.n_blocks = (uint32_t)n_blocks;
+    const bool stats = (c->prm.flags & MRTX_F_COUNT_STATS) != 0;
+    if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->blocks_done += (uint32_t)n_blocks;
+    if (out) {
+        std::memset(out, 0, sizeof *out);
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        out->kernel_ms = ms;
+        out->launches = 1;
+        if (stats) {
+            unsigned long long h[8];
+            HIPCHK(c, hipMemcpy(h, c->stats_dev, sizeof h, hipMemcpyDeviceToHost));
+            out->primary_rays = h[0]; out->primary_hits = h[1]; out->shadow_rays = h[2];
+            out->height_samples = h[3]; out->colour_fetches = h[4]; out->background_fetches = h[5];
+        }
+    }
+    return MRTX_OK;
+}
+
+int mrtx_samples_done(mrtx_ctx* c, uint32_t* out) {
+    if (!c || !out) return MRTX_E_INVALID;
+    *out = c->blocks_done * c->prm.spp_per_launch;
+    return MRTX_OK;
+}
+
+int mrtx_read_linear(mrtx_ctx* c, float* out) {
+    if (!c || !out) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int64_t npix = (int64_t)c->cfg.width * c->cfg.height;
+    HIPCHK(c, mrtx_launch_resolve_linear(c->accum, (float*)c->scratch, npix, c->blocks_done * c->prm.spp_per_launch, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->scratch, (size_t)npix * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MRTX_OK;
+}
+int mrtx_read_rgba8(mrtx_ctx* c, uint8_t* out) {
+    if (!c || !out) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int64_t npix = (int64_t)c->cfg.width * c->cfg.height;
+    HIPCHK(c, mrtx_launch_resolve_rgba8(c->accum, (uint32_t*)c->scratch, npix, c->blocks_done * c->prm.spp_per_launch,
+                                        c->prm.tonemap_exposure, 1.0f / c->prm.tonemap_gamma, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->scratch, (size_t)npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MRTX_OK;
+}
+int mrtx_read_hits(mrtx_ctx* c, float* out) {
+    if (!c || !out) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t bytes = (size_t)c->cfg.width * c->cfg.height * 16;
+    HIPCHK(c, hipMemcpyAsync(out, c->hits, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MRTX_OK;
+}
+
+int mrtx_shard_bytes(mrtx_ctx* c, int32_t rank, uint64_t* out) {
+    if (!c || !out || rank < 0 || rank >= c->cfg.world) return MRTX_E_INVALID;
+    *out = (uint64_t)c->slots * c->cfg.tile_w * c->cfg.tile_h * 32ull;  // equal for every rank (padded)
+    return MRTX_OK;
+}
+int mrtx_pack_shard(mrtx_ctx* c, void* dev_dst, void* hip_stream) {
+    if (!c || !dev_dst) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HIPCHK(c, mrtx_launch_pack(c->accum, c->hits, dev_dst, c->cfg.width, c->cfg.height, c->cfg.tile_w, c->cfg.tile_h,
+                               c->tiles_x, c->n_tiles, c->cfg.rank, c->cfg.world, c->slots, st));
+    if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
+    return MRTX_OK;
+}
+int mrtx_unpack_shard(mrtx_ctx* c, int32_t src_rank, const void* dev_src, void* hip_stream) {
+    if (!c || !dev_src || src_rank < 0 || src_rank >= c->cfg.world) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HIPCHK(c, mrtx_launch_unpack(c->accum, c->hits, dev_src, c->cfg.width, c->cfg.height, c->cfg.tile_w,
+                                 c->cfg.tile_h, c->tiles_x, c->n_tiles, src_rank, c->cfg.world, c->slots, st));
+    if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
+    return MRTX_OK;
+}
+
+int mrtx_device_ptr(mrtx_ctx* c, int32_t which, void** out, uint64_t* bytes) {
+    if (!c || !out) return MRTX_E_INVALID;
+    const uint64_t fb = (uint64_t)c->cfg.width * c->cfg.height * 16;
+    switch (which) {
+        case MRTX_BUF_ACCUM: *out = c->accum; if (bytes) *bytes = fb; break;
+        case MRTX_BUF_HITS: *out = c->hits; if (bytes) *bytes = fb; break;
+        case MRTX_BUF_DEM: *out = c->dem; if (bytes) *bytes = (uint64_t)c->dem_h * c->dem_w * 4; break;
+        case MRTX_BUF_COLOR: *out = c->color; if (bytes) *bytes = (uint64_t)c->color_h * c->color_w * 4; break;
+        default: return fail(c, MRTX_E_INVALID, "unknown buffer id %d", which);
+    }
+    return MRTX_OK;
+}
+
+// ---- context-free helpers ---------------------------------------------------------------------
+static int efail(char* err, int32_t n, const char* what, hipError_t e) {
+    if (err && n > 0) snprintf(err, (size_t)n, "%s: %s", what, hipGetErrorString(e));
+    return MRTX_E_DEVICE;
+}
+#define HIPCHK2(call)                                       \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return efail(err, err_len, #call, e_); \
+    } while (0)
+
+int mrtx_dem_from_ldem(int32_t device, const void* src, int32_t h, int32_t w, int32_t d, void* dst,
+                       float* radius_scale, char* err, int32_t err_len) {
+    if (!src || !dst || h < 1 || w < 1 || d < 1 || d > 64) return MRTX_E_INVALID;
+    HIPCHK2(hipSetDevice(device));
+    unsigned int* mb = nullptr;
+    HIPCHK2(hipMalloc((void**)&mb, sizeof(unsigned int)));
+    HIPCHK2(hipMemset(mb, 0, sizeof(unsigned int)));
+    hipError_t e = mrtx_launch_ldem((const int16_t*)src, (float*)dst, h, w, d, mb, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned int bits = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bits, mb, sizeof bits, hipMemcpyDeviceToHost);
+    (void)hipFree(mb);
+    if (e != hipSuccess) return efail(err, err_len, "ldem kernels", e);
+    if (radius_scale) std::memcpy(radius_scale, &bits, sizeof(float));
+    return MRTX_OK;
+}
+int mrtx_synth_ldem(int32_t device, void* dst, int32_t h, int32_t w, uint32_t seed, char* err, int32_t err_len) {
+    if (!dst || h < 1 || w < 1) return MRTX_E_INVALID;
+    HIPCHK2(hipSetDevice(device));
+    HIPCHK2(mrtx_launch_synth_ldem((int16_t*)dst, h, w, seed, nullptr));
+    HIPCHK2(hipDeviceSynchronize());
+    return MRTX_OK;
+}
+int mrtx_synth_color(int32_t device, void* dst, int32_t h, int32_t w, uint32_t seed, char* err, int32_t err_len) {
+    if (!dst || h < 1 || w < 1) return MRTX_E_INVALID;
+    HIPCHK2(hipSetDevice(device));
+    HIPCHK2(mrtx_launch_synth_color((uint32_t*)dst, h, w, seed, nullptr));
+    HIPCHK2(hipDeviceSynchronize());
+    return MRTX_OK;
+}
+int mrtx_dev_alloc(int32_t device, uint64_t bytes, void** out) {
+    if (!out || bytes == 0) return MRTX_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
+    return hipMalloc(out, (size_t)bytes) == hipSuccess ? MRTX_OK : MRTX_E_NOMEM;
+}
+int mrtx_dev_free(int32_t device, void* p) {
+    if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
+    return hipFree(p) == hipSuccess ? MRTX_OK : MRTX_E_DEVICE;
+}
+int mrtx_dev_download(int32_t device, void* host_dst, const void* dev_src, uint64_t bytes) {
+    if (!host_dst || !dev_src) return MRTX_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
+    return hipMemcpy(host_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToHost) == hipSuccess ? MRTX_OK : MRTX_E_DEVICE;
+}
+int mrtx_dev_upload(int32_t device, void* dev_dst, const void* host_src, uint64_t bytes) {
+    if (!dev_dst || !host_src) return MRTX_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
+    return hipMemcpy(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice) == hipSuccess ? MRTX_OK : MRTX_E_DEVICE;
+}
+int mrtx_probe_atan2(int32_t device, const float* y, const float* x, float* out, int32_t n) {
+    if (!y || !x || !out || n < 1) return MRTX_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
+    float *dy = nullptr, *dx = nullptr, *dout = nullptr;
+    const size_t b = (size_t)n * sizeof(float);
+    int rc = MRTX_E_DEVICE;
+    if (hipMalloc((void**)&dy, b) == hipSuccess && hipMalloc((void**)&dx, b) == hipSuccess &&
+        hipMalloc((void**)&dout, b) == hipSuccess && hipMemcpy(dy, y, b, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dx, x, b, hipMemcpyHostToDevice) == hipSuccess &&
+        mrtx_launch_probe_atan2(dy, dx, dout, n, nullptr) == hipSuccess &&
+        hipMemcpy(out, dout, b, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = MRTX_OK;
+    if (dy) (void)hipFree(dy);
+    if (dx) (void)hipFree(dx);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// mrtx_device.h -- data shared by the host side of libmoonrt.so and its gfx950 kernels.
+//
+// FrameC is the per-launch constant block: everything the kernels need, derived once on the host in
+// float64 from the calls the reference makes on its renderer object (moon_renderer.py:570-650 for the
+// static scene, :824-871 for the per-time-step update) and handed to the kernel BY VALUE, so the
+// compiler keeps it in SGPRs (wave-uniform scalar loads, no VGPR cost).
+#pragma once
+#include <stdint.h>
+
+struct GridC {          // equirectangular grid: row 0 = +90 deg, column 0 = -180 deg
+    int32_t h, w;       // (renderer_navigation.py:575-593)
+    float row_scale, row_off, col_scale, col_off, wf;
+};
+
+struct FrameC {
+    int32_t W, H;
+    // D1 pinhole camera (moon_renderer.py:627-635)
+    float Wd[3], Ux[3], Vy[3], two_over_w, two_over_h;
+    double oc[3], cq;       // eye - centre, |oc|^2 - R^2
+    double M[3][3];         // scene -> moon frame, rows = (east 90, lon 0, north)
+    float Mf[3][3], centerf[3], eyef[3];
+    float Rf, R2f;
+    // D5 light (moon_renderer.py:640-641, :859-860)
+    float Lb[3], rL2, rad2;
+    // D8 Sun disk (moon_renderer.py:647-650)
+    int32_t sun_on;
+    float sc[3], sun_cq, sun_rad;
+    // D2 march (moon_renderer.py:586-588)
+    float step, eps, scene_eps;
+    int32_t nbis, kmax;
+    float dlat_scale, dlon_scale;
+    GridC gd, gc;
+    int32_t bg_h, bg_w;
+    float bg_row_scale, bg_row_off, bg_col_scale, bg_col_off;
+    uint32_t key0;
+    float const_albedo[3];
+    const float* dem;
+    const uint8_t* color;   // RGBA8 or null
+    const uint8_t* bg;      // RGBA8 or null
+    // image-tile sharding (new) + accumulation state
+    int32_t tile_w, tile_h, tiles_x, tiles_y, rank, world, n_local_tiles;
+    uint32_t first_block, n_blocks;
+    float* accum;           // W*H float4: running sums r,g,b,coverage
+    float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block
+    unsigned long long* stats;  // 6 counters, see MrtxStats
+};

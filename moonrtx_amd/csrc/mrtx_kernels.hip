@@ -1,0 +1,696 @@
+// mrtx_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of libmoonrt.so.
+//
+// What runs here replaces the device programs PlotOptiX launches for MoonRTX's one scene (SURVEY.md
+// section 2.1, D1-D10): pinhole ray generation, the height-field march of the displaced sphere, the
+// bilinear equirect DEM / colour fetches, Lambert shading against one sample of the spherical Sun
+// light with a marched shadow ray, Sun-disk / environment on a miss, accumulation and the hit buffer.
+//
+// MI355X mapping:
+//   * a 64-lane wavefront IS the 64 samples of one pixel (spp_per_launch = 64): the 64 rays differ
+//     only by sub-pixel jitter, so they walk the same DEM cache lines and leave the march loops on
+//     nearly the same step -- the wave-wide `while (any lane active)` the compiler emits for the
+//     march (s_cbranch_execnz on the ballot of live lanes) wastes almost nothing, and the sample
+//     mean is an in-register xor-butterfly, not a read-modify-write on HBM;
+//   * smaller spp_per_launch packs 64/S neighbouring pixels into the wave the same way;
+//   * workgroups are dealt to image tiles through an XCD-aware remap so that the ~8 workgroups an
+//     XCD runs at a time work inside one 32x32-pixel tile and share its DEM footprint in that
+//     XCD's 4 MiB L2;
+//   * FrameC comes by value -> SGPRs; no LDS, no MFMA (nothing here is a dense contraction).
+//
+// Arithmetic follows the spec of DESIGN.md section 3 operation by operation: explicit fmaf, build
+// with -ffp-contract=off, correctly rounded / and sqrt (hipcc default), own polynomial atan/sin/cos.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mrtx_device.h"
+
+namespace mrtx {
+
+__device__ constexpr float kPi = 3.14159274101257324f;
+__device__ constexpr float kHalfPi = 1.57079637050628662f;
+
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_N };
+
+// atan(q) ~= q * P(q^2) on [0,1]; full-quadrant atan2 by reflection.  |err| <= 1.3e-7.
+__device__ __forceinline__ float atan2_poly(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay;
+    const float mn = ax > ay ? ay : ax;
+    const float q = (mx == 0.0f) ? 0.0f : mn / mx;
+    const float s = q * q;
+    float p = -0.004054343327879906f;
+    p = fmaf(p, s, 0.02186218835413456f);
+    p = fmaf(p, s, -0.05591127648949623f);
+    p = fmaf(p, s, 0.0964212492108345f);
+    p = fmaf(p, s, -0.1390860229730606f);
+    p = fmaf(p, s, 0.19946560263633728f);
+    p = fmaf(p, s, -0.33329859375953674f);
+    p = fmaf(p, s, 0.9999993443489075f);
+    float r = p * q;
+    if (ay > ax) r = kHalfPi - r;
+    if (x < 0.0f) r = kPi - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+// cos / sin of 2*pi*u, u in [0,1): quadrant split + polynomials on [0, pi/2)
+__device__ __forceinline__ void sincos_turn(float u, float& cs, float& sn) {
+    const float t4 = u * 4.0f;
+    const float qf = floorf(t4);
+    const float a = (t4 - qf) * kHalfPi;
+    const float a2 = a * a;
+    float sp = 2.590481244624243e-06f;
+    sp = fmaf(sp, a2, -0.00019800894369836897f);
+    sp = fmaf(sp, a2, 0.008332899771630764f);
+    sp = fmaf(sp, a2, -0.16666647791862488f);
+    sp = fmaf(sp, a2, 1.0f);
+    const float s1 = sp * a;
+    float cp = 2.3153859729063697e-05f;
+    cp = fmaf(cp, a2, -0.001385370153002441f);
+    cp = fmaf(cp, a2, 0.04166358336806297f);
+    cp = fmaf(cp, a2, -0.4999990463256836f);
+    cp = fmaf(cp, a2, 0.9999999403953552f);
+    const float c1 = cp;
+    const int qi = (int)qf;
+    cs = qi == 0 ? c1 : (qi == 1 ? -s1 : (qi == 2 ? -c1 : s1));
+    sn = qi == 0 ? s1 : (qi == 1 ? c1 : (qi == 2 ? -s1 : -c1));
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float u01(uint32_t key, uint32_t dim) {
+    const uint32_t r = mix32(key + (dim + 1u) * 0x9E3779B9u);
+    return (float)(r >> 8) * 5.9604644775390625e-08f;
+}
+
+struct Tap {
+    int64_t i00, i01, i10, i11;
+    float fr, fc;
+};
+
+// texel coordinates -> four taps; rows clamp, columns wrap at the +/-180 seam
+// (renderer_navigation.py:581-588)
+__device__ __forceinline__ Tap grid_tap(const GridC& g, float rowf, float colf) {
+    if (colf < 0.0f) colf += g.wf;
+    if (colf >= g.wf) colf -= g.wf;
+    const float rfl = floorf(rowf);
+    int32_t r0 = (int32_t)rfl;
+    r0 = r0 < 0 ? 0 : (r0 > g.h - 2 ? g.h - 2 : r0);
+    float fr = rowf - (float)r0;
+    fr = fr < 0.0f ? 0.0f : (fr > 1.0f ? 1.0f : fr);
+    const float cfl = floorf(colf);
+    int32_t c0 = (int32_t)cfl;
+    const float fc = colf - cfl;
+    if (c0 >= g.w) c0 -= g.w;
+    int32_t c1 = c0 + 1;
+    if (c1 >= g.w) c1 = 0;
+    const int64_t b0 = (int64_t)r0 * g.w, b1 = b0 + g.w;
+    Tap t;
+    t.i00 = b0 + c0; t.i01 = b0 + c1; t.i10 = b1 + c0; t.i11 = b1 + c1;
+    t.fr = fr; t.fc = fc;
+    return t;
+}
+__device__ __forceinline__ float lerp2(float e00, float e01, float e10, float e11, float fr, float fc) {
+    const float top = fmaf(fc, e01 - e00, e00);
+    const float bot = fmaf(fc, e11 - e10, e10);
+    return fmaf(fr, bot - top, top);
+}
+__device__ __forceinline__ float dem_at(const float* __restrict__ dem, const GridC& g, float rowf, float colf) {
+    const Tap t = grid_tap(g, rowf, colf);
+    return lerp2(dem[t.i00], dem[t.i01], dem[t.i10], dem[t.i11], t.fr, t.fc);
+}
+
+// D2/D3: is the point (moon frame) at or below the displaced surface?  r^2 <= (R * D(lat,lon))^2
+template <bool STATS>
+__device__ __forceinline__ bool below_surface(const FrameC& f, float pa, float pb, float pc, uint32_t* cnt) {
+    const float rho2 = fmaf(pb, pb, pa * pa);
+    const float r2 = fmaf(pc, pc, rho2);
+    const float rho = sqrtf(rho2);
+    const float lat = atan2_poly(pc, rho);
+    const float lon = atan2_poly(pa, pb);
+    const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
+    const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
+    const float d = dem_at(f.dem, f.gd, rowf, colf);
+    if (STATS) cnt[ST_HEIGHT]++;
+    const float surf = f.Rf * d;
+    return r2 <= surf * surf;
+}
+
+struct SampleOut {
+    float c0, c1, c2, hitflag;
+    float h0, h1, h2, h3;
+};
+
+template <bool STATS>
+__device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint32_t gs, SampleOut& o,
+                                             uint32_t* cnt) {
+    const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
+    const uint32_t kp = mix32(pix + f.key0);
+    const uint32_t ks = mix32(kp ^ (gs * 0x85EBCA6Bu + 1u));
+    const float u0 = u01(ks, 0), u1 = u01(ks, 1), u2 = u01(ks, 2), u3 = u01(ks, 3);
+    o.c0 = o.c1 = o.c2 = 0.0f; o.hitflag = 0.0f;
+    o.h0 = o.h1 = o.h2 = o.h3 = 0.0f;
+    if (STATS) cnt[ST_PRIMARY]++;
+
+    // D1: jittered pinhole ray
+    const float fx = (float)x + u0, fy = (float)y + u1;
+    const float sx = fmaf(fx, f.two_over_w, -1.0f);
+    const float sy = fmaf(-fy, f.two_over_h, 1.0f);
+    float dx = fmaf(sy, f.Vy[0], fmaf(sx, f.Ux[0], f.Wd[0]));
+    float dy = fmaf(sy, f.Vy[1], fmaf(sx, f.Ux[1], f.Wd[1]));
+    float dz = fmaf(sy, f.Vy[2], fmaf(sx, f.Ux[2], f.Wd[2]));
+    const float len = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    dx = dx / len; dy = dy / len; dz = dz / len;
+
+    // float64 entry into the bounding sphere: the eye sits ~30 radii away, float32 would cost metres
+    const double Dx = (double)dx, Dy = (double)dy, Dz = (double)dz;
+    const double a = (Dx * Dx + Dy * Dy) + Dz * Dz;
+    const double b = (f.oc[0] * Dx + f.oc[1] * Dy) + f.oc[2] * Dz;
+    const double disc = b * b - a * f.cq;
+    bool on_sphere = false;
+    double t0 = 0.0, t1 = 0.0;
+    if (disc > 0.0) {
+        const double sq = sqrt(disc);
+        t0 = (-b - sq) / a;
+        t1 = (-b + sq) / a;
+        if (t1 > 0.0) { on_sphere = true; if (t0 < 0.0) t0 = 0.0; }
+    }
+    bool hit = false;
+    float pa = 0.f, pb = 0.f, pc = 0.f, da = 0.f, db = 0.f, dc = 0.f, lo = 0.0f;
+    if (on_sphere) {
+        const double pe0 = f.oc[0] + t0 * Dx, pe1 = f.oc[1] + t0 * Dy, pe2 = f.oc[2] + t0 * Dz;
+        pa = (float)((f.M[0][0] * pe0 + f.M[0][1] * pe1) + f.M[0][2] * pe2);
+        pb = (float)((f.M[1][0] * pe0 + f.M[1][1] * pe1) + f.M[1][2] * pe2);
+        pc = (float)((f.M[2][0] * pe0 + f.M[2][1] * pe1) + f.M[2][2] * pe2);
+        da = (float)((f.M[0][0] * Dx + f.M[0][1] * Dy) + f.M[0][2] * Dz);
+        db = (float)((f.M[1][0] * Dx + f.M[1][1] * Dy) + f.M[1][2] * Dz);
+        dc = (float)((f.M[2][0] * Dx + f.M[2][1] * Dy) + f.M[2][2] * Dz);
+        const float smax = (float)(t1 - t0);
+        float hi = 0.0f;
+        for (int k = 1; k <= f.kmax; k++) {
+            const float sk = (float)k * f.step;
+            if (sk > smax) break;
+            if (below_surface<STATS>(f, fmaf(sk, da, pa), fmaf(sk, db, pb), fmaf(sk, dc, pc), cnt)) {
+                hit = true; hi = sk; lo = (float)(k - 1) * f.step;
+                break;
+            }
+        }
+        if (hit) {
+            for (int i = 0; i < f.nbis; i++) {
+                const float mid = 0.5f * (lo + hi);
+                if (below_surface<STATS>(f, fmaf(mid, da, pa), fmaf(mid, db, pb), fmaf(mid, dc, pc), cnt)) hi = mid;
+                else lo = mid;
+            }
+        }
+    }
+
+    if (!hit) {
+        if (f.sun_on) {  // D8
+            const float bq = fmaf(f.sc[2], dz, fmaf(f.sc[1], dy, f.sc[0] * dx));
+            const float dq = fmaf(bq, bq, -f.sun_cq);
+            if (bq > 0.0f && dq > 0.0f) {
+                const float t = bq - sqrtf(dq);
+                o.c0 = o.c1 = o.c2 = f.sun_rad;
+                o.hitflag = 1.0f;
+                o.h0 = fmaf(t, dx, f.eyef[0]);
+                o.h1 = fmaf(t, dy, f.eyef[1]);
+                o.h2 = fmaf(t, dz, f.eyef[2]);
+                o.h3 = t;
+                return;
+            }
+        }
+        if (f.bg) {  // D7
+            const float rho = sqrtf(fmaf(dy, dy, dx * dx));
+            const float el = atan2_poly(dz, rho);
+            const float az = atan2_poly(dx, dy);
+            const float rowf = fmaf(el, f.bg_row_scale, f.bg_row_off);
+            const float colf = fmaf(az, f.bg_col_scale, f.bg_col_off);
+            int r = (int)floorf(rowf), c = (int)floorf(colf);
+            r = r < 0 ? 0 : (r > f.bg_h - 1 ? f.bg_h - 1 : r);
+            if (c >= f.bg_w) c -= f.bg_w;
+            if (c < 0) c = 0;
+            const uint32_t px = reinterpret_cast<const uint32_t*>(f.bg)[(int64_t)r * f.bg_w + c];
+            o.c0 = (float)(px & 255u) / 255.0f;
+            o.c1 = (float)((px >> 8) & 255u) / 255.0f;
+            o.c2 = (float)((px >> 16) & 255u) / 255.0f;
+            if (STATS) cnt[ST_BG]++;
+        }
+        return;
+    }
+
+    // ---- hit point, normal from central differences of D, albedo
+    if (STATS) cnt[ST_HITS]++;
+    const float ha = fmaf(lo, da, pa), hb = fmaf(lo, db, pb), hc = fmaf(lo, dc, pc);
+    const float rho2 = fmaf(hb, hb, ha * ha);
+    const float r2 = fmaf(hc, hc, rho2);
+    const float rho = sqrtf(rho2);
+    const float r = sqrtf(r2);
+    const float lat = atan2_poly(hc, rho);
+    const float lon = atan2_poly(ha, hb);
+    const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
+    const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
+    const float dn = dem_at(f.dem, f.gd, rowf - 1.0f, colf);
+    const float ds = dem_at(f.dem, f.gd, rowf + 1.0f, colf);
+    const float de = dem_at(f.dem, f.gd, rowf, colf + 1.0f);
+    const float dw = dem_at(f.dem, f.gd, rowf, colf - 1.0f);
+    if (STATS) cnt[ST_HEIGHT] += 4;
+    const float dlat = (dn - ds) * f.dlat_scale;
+    const float dlon = (de - dw) * f.dlon_scale;
+    const float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
+    const float inv_r = 1.0f / r, inv_rho = 1.0f / rhoc;
+    const float sphi = hc * inv_r, cphi = rhoc * inv_r;
+    const float slam = ha * inv_rho, clam = hb * inv_rho;
+    const float glat = (f.Rf * inv_r) * dlat;
+    const float glon = (f.Rf * inv_rho) * dlon;
+    float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
+    float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
+    float nc = fmaf(-glat, cphi, hc * inv_r);
+    const float nl = sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
+    na = na / nl; nb = nb / nl; nc = nc / nl;
+
+    float al0, al1, al2;
+    if (f.color) {  // D4: bilinear RGBA8
+        const float rc = fmaf(lat, f.gc.row_scale, f.gc.row_off);
+        const float cc = fmaf(lon, f.gc.col_scale, f.gc.col_off);
+        const Tap t = grid_tap(f.gc, rc, cc);
+        const uint32_t* tex = reinterpret_cast<const uint32_t*>(f.color);
+        const uint32_t p00 = tex[t.i00], p01 = tex[t.i01], p10 = tex[t.i10], p11 = tex[t.i11];
+        al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), t.fr, t.fc) / 255.0f;
+        al1 = lerp2((float)((p00 >> 8) & 255u), (float)((p01 >> 8) & 255u), (float)((p10 >> 8) & 255u),
+                    (float)((p11 >> 8) & 255u), t.fr, t.fc) / 255.0f;
+        al2 = lerp2((float)((p00 >> 16) & 255u), (float)((p01 >> 16) & 255u), (float)((p10 >> 16) & 255u),
+                    (float)((p11 >> 16) & 255u), t.fr, t.fc) / 255.0f;
+        if (STATS) cnt[ST_COLOUR]++;
+    } else {
+        al0 = f.const_albedo[0]; al1 = f.const_albedo[1]; al2 = f.const_albedo[2];
+    }
+
+    o.hitflag = 1.0f;
+    o.h0 = f.centerf[0] + fmaf(hc, f.Mf[2][0], fmaf(hb, f.Mf[1][0], ha * f.Mf[0][0]));
+    o.h1 = f.centerf[1] + fmaf(hc, f.Mf[2][1], fmaf(hb, f.Mf[1][1], ha * f.Mf[0][1]));
+    o.h2 = f.centerf[2] + fmaf(hc, f.Mf[2][2], fmaf(hb, f.Mf[1][2], ha * f.Mf[0][2]));
+    o.h3 = (float)t0 + lo;
+
+    // ---- D5: one sample of the spherical light, shadow ray marched through the same height field
+    const float eps = f.scene_eps;
+    const float oa = fmaf(eps, na, ha), ob = fmaf(eps, nb, hb), oc = fmaf(eps, nc, hc);
+    const float ta = f.Lb[0] - oa, tb = f.Lb[1] - ob, tc = f.Lb[2] - oc;
+    const float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
+    const float dist = sqrtf(d2);
+    const float la = ta / dist, lb = tb / dist, lc = tc / dist;
+    float sin2 = f.rL2 / d2;
+    if (sin2 > 1.0f) sin2 = 1.0f;
+    const float cosmax = sqrtf(1.0f - sin2);
+    const float omc = sin2 / (1.0f + cosmax);
+    const float av = u2 * omc;
+    const float cost = 1.0f - av;
+    const float sint = sqrtf(av * (2.0f - av));
+    float cph, sph;
+    sincos_turn(u3, cph, sph);
+    const float sg = lc >= 0.0f ? 1.0f : -1.0f;
+    const float aa = -1.0f / (sg + lc);
+    const float bb = (la * lb) * aa;
+    const float b1a = fmaf(sg, (la * la) * aa, 1.0f), b1b = sg * bb, b1c = -sg * la;
+    const float b2a = bb, b2b = fmaf(lb * lb, aa, sg), b2c = -lb;
+    const float ca = sint * cph, sa = sint * sph;
+    const float wa = fmaf(cost, la, fmaf(sa, b2a, ca * b1a));
+    const float wb = fmaf(cost, lb, fmaf(sa, b2b, ca * b1b));
+    const float wc = fmaf(cost, lc, fmaf(sa, b2c, ca * b1c));
+    const float cosi = fmaf(nc, wc, fmaf(nb, wb, na * wa));
+    if (!(cosi > 0.0f)) return;
+
+    if (STATS) cnt[ST_SHADOW]++;
+    bool lit = true;
+    for (int k = 1; k <= f.kmax; k++) {
+        const float sk = (float)k * f.step;
+        const float qa = fmaf(sk, wa, oa), qb = fmaf(sk, wb, ob), qc = fmaf(sk, wc, oc);
+        const float q2 = fmaf(qc, qc, fmaf(qb, qb, qa * qa));
+        if (q2 > f.R2f) break;
+        if (below_surface<STATS>(f, qa, qb, qc, cnt)) { lit = false; break; }
+    }
+    if (!lit) return;
+    const float wgt = (f.rad2 * omc) * cosi;
+    o.c0 = al0 * wgt; o.c1 = al1 * wgt; o.c2 = al2 * wgt;
+}
+
+template <int S>
+__device__ __forceinline__ float tree_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < S; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// One wave = 64 (pixel, sample) pairs: P = 64/S pixels (PW x PH block) x S samples in adjacent lanes.
+// One 256-thread workgroup = one 16x16-pixel sub-tile of a sharding tile.
+template <int S, bool STATS>
+__global__ void __launch_bounds__(256) render_kernel(const FrameC f) {
+    constexpr int P = 64 / S;
+    constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;
+    constexpr int PH = P / PW;
+    constexpr int JX = 16 / PW, JY = 16 / PH, NJOBS = JX * JY;
+    __shared__ unsigned int lds_cnt[ST_N];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // XCD-aware remap: consecutive blockIdx values go to XCDs round-robin, so block b and b+8 share
+    // an XCD (and its L2).  Give XCD x the sharding tiles x, x+8, x+16, ... and let it walk the
+    // sub-tiles of one tile back to back.
+    const int subs_x = f.tile_w >> 4, subs = subs_x * (f.tile_h >> 4);
+    const int b = blockIdx.x, xcd = b & 7, g = b >> 3;
+    const int lt = (g / subs) * 8 + xcd, sub = g % subs;
+    if (lt >= f.n_local_tiles) return;
+    const int t = lt * f.world + f.rank;
+    const int tx = t % f.tiles_x, ty = t / f.tiles_x;
+    const int px0 = tx * f.tile_w + (sub % subs_x) * 16, py0 = ty * f.tile_h + (sub / subs_x) * 16;
+    if (px0 >= f.W || py0 >= f.H) return;
+
+    uint32_t cnt[ST_N];
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_N; i++) cnt[i] = 0;
+        if (threadIdx.x < ST_N) lds_cnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
+
+    const int p = lane / S, s = lane % S;
+    for (int job = wv; job < NJOBS; job += 4) {
+        const int jx = job % JX, jy = job / JX;
+        const int x = px0 + jx * PW + (p % PW), y = py0 + jy * PH + (p / PW);
+        if (px0 + jx * PW >= f.W || py0 + jy * PH >= f.H) continue;  // wave-uniform
+        const bool inb = x < f.W && y < f.H;
+        const int64_t pix = (int64_t)y * f.W + x;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (f.first_block != 0 && inb) {
+            const float4 prev = reinterpret_cast<const float4*>(f.accum)[pix];
+            s0 = prev.x; s1 = prev.y; s2 = prev.z; s3 = prev.w;
+        }
+        SampleOut o;
+        o.h0 = o.h1 = o.h2 = o.h3 = 0.f;
+        for (uint32_t blk = 0; blk < f.n_blocks; blk++) {
+            o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
+            if (inb) trace_sample<STATS>(f, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            s0 += tree_sum<S>(o.c0);
+            s1 += tree_sum<S>(o.c1);
+            s2 += tree_sum<S>(o.c2);
+            s3 += tree_sum<S>(o.hitflag);
+        }
+        if (inb && s == 0) {
+            reinterpret_cast<float4*>(f.accum)[pix] = make_float4(s0, s1, s2, s3);
+            reinterpret_cast<float4*>(f.hits)[pix] = make_float4(o.h0, o.h1, o.h2, o.h3);
+        }
+    }
+
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_N; i++) {
+            uint32_t v = cnt[i];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) atomicAdd(&lds_cnt[i], v);
+        }
+        __syncthreads();
+        if (threadIdx.x < ST_N) atomicAdd(&f.stats[threadIdx.x], (unsigned long long)lds_cnt[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// resolve: running sums -> mean linear radiance; "Gamma" post-process -> RGBA8
+__global__ void resolve_linear_kernel(const float4* __restrict__ accum, float4* __restrict__ out, int64_t n,
+                                      uint32_t nsamples) {
+    const float ns = (float)nsamples;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = accum[i];
+        out[i] = nsamples ? make_float4(a.x / ns, a.y / ns, a.z / ns, a.w / ns) : make_float4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ uint32_t tone8(float v, float expo, float invg) {
+    float t = powf(fmaxf(expo * v, 0.0f), invg);
+    t = fminf(t, 1.0f);
+    return (uint32_t)floorf(fmaf(t, 255.0f, 0.5f));
+}
+__global__ void resolve_rgba8_kernel(const float4* __restrict__ accum, uint32_t* __restrict__ out, int64_t n,
+                                     uint32_t nsamples, float expo, float invg) {
+    const float ns = (float)nsamples;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = accum[i];
+        uint32_t px = 0xFF000000u;
+        if (nsamples) px |= tone8(a.x / ns, expo, invg) | (tone8(a.y / ns, expo, invg) << 8) | (tone8(a.z / ns, expo, invg) << 16);
+        out[i] = px;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU exchange: pack the tiles a rank owns into a dense buffer / scatter a peer's buffer back.
+// Layout of a packed shard: [slot][tile_h][tile_w] float4 sums, then the same for hits; slot k of
+// rank r is tile k*world + r.  Both directions move whole float4 (16 B/lane, coalesced).
+__global__ void pack_shard_kernel(const float4* __restrict__ accum, const float4* __restrict__ hits,
+                                  float4* __restrict__ dst, int W, int H, int tile_w, int tile_h, int tiles_x,
+                                  int n_tiles, int rank, int world, int slots) {
+    const int tile_px = tile_w * tile_h;
+    const int64_t total = (int64_t)slots * tile_px;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i / tile_px), r = (int)(i % tile_px);
+        const int t = slot * world + rank;
+        float4 a = make_float4(0, 0, 0, 0), h = a;
+        if (t < n_tiles) {
+            const int x = (t % tiles_x) * tile_w + r % tile_w, y = (t / tiles_x) * tile_h + r / tile_w;
+            if (x < W && y < H) { a = accum[(int64_t)y * W + x]; h = hits[(int64_t)y * W + x]; }
+        }
+        dst[i] = a;
+        dst[total + i] = h;
+    }
+}
+__global__ void unpack_shard_kernel(float4* __restrict__ accum, float4* __restrict__ hits,
+                                    const float4* __restrict__ src, int W, int H, int tile_w, int tile_h,
+                                    int tiles_x, int n_tiles, int src_rank, int world, int slots) {
+    const int tile_px = tile_w * tile_h;
+    const int64_t total = (int64_t)slots * tile_px;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i / tile_px), r = (int)(i % tile_px);
+        const int t = slot * world + src_rank;
+        if (t >= n_tiles) continue;
+        const int x = (t % tiles_x) * tile_w + r % tile_w, y = (t / tiles_x) * tile_h + r / tile_w;
+        if (x < W && y < H) { accum[(int64_t)y * W + x] = src[i]; hits[(int64_t)y * W + x] = src[total + i]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ingest: data_loader.py:166-247 on the device.  One thread per output texel; the d x d int16 block
+// is read as d row segments (for d <= 8 a segment is <= 16 B).  Integer sums of <= 8 int16 are exact
+// in float32, so stage 1 is order-free; stage 2 adds the d row means in row order.
+__global__ void ldem_block_mean_kernel(const int16_t* __restrict__ src, float* __restrict__ dst, int h, int w,
+                                       int d, unsigned int* __restrict__ max_bits) {
+    const float scale = (float)(0.5 / 1737400.0);
+    const int64_t n = (int64_t)h * w, Wsrc = (int64_t)w * d;
+    float mx = 0.0f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / w), c = (int)(i % w);
+        float v;
+        if (d == 1) {
+            v = (float)src[i] * scale;
+        } else {
+            float acc2 = 0.0f;
+            for (int ii = 0; ii < d; ii++) {
+                const int16_t* p = src + ((int64_t)r * d + ii) * Wsrc + (int64_t)c * d;
+                float acc = 0.0f;
+                for (int j = 0; j < d; j++) acc += (float)p[j];
+                acc = acc / (float)d;
+                acc2 = (ii == 0) ? acc : acc2 + acc;
+            }
+            v = (acc2 / (float)d) * scale;
+        }
+        v += 1.0f;
+        dst[i] = v;
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(mx));  // v > 0: uint order == float order
+}
+__global__ void scale_by_inv_kernel(float* __restrict__ dst, int64_t n, const unsigned int* __restrict__ max_bits) {
+    const float mx = __uint_as_float(*max_bits);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = dst[i] / mx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic inputs (bench / test data): fractal value noise on the sphere +
+// hashed crater field, in LDEM units (0.5 m), clipped to the LOLA-like range.
+__device__ __forceinline__ float hash01(int x, int y, int z, uint32_t seed) {
+    const uint32_t h = mix32((uint32_t)x * 0x8da6b343u ^ (uint32_t)y * 0xd8163841u ^ (uint32_t)z * 0xcb1ab31fu ^ seed);
+    return (float)(h >> 8) * 5.9604644775390625e-08f;
+}
+__device__ float vnoise3(float x, float y, float z, uint32_t seed) {
+    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    float tx = x - fx, ty = y - fy, tz = z - fz;
+    tx = tx * tx * (3.f - 2.f * tx); ty = ty * ty * (3.f - 2.f * ty); tz = tz * tz * (3.f - 2.f * tz);
+    float c[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) c[i][j][k] = hash01(ix + i, iy + j, iz + k, seed);
+    const float x00 = c[0][0][0] + tx * (c[1][0][0] - c[0][0][0]), x10 = c[0][1][0] + tx * (c[1][1][0] - c[0][1][0]);
+    const float x01 = c[0][0][1] + tx * (c[1][0][1] - c[0][0][1]), x11 = c[0][1][1] + tx * (c[1][1][1] - c[0][1][1]);
+    const float y0 = x00 + ty * (x10 - x00), y1 = x01 + ty * (x11 - x01);
+    return 2.0f * (y0 + tz * (y1 - y0)) - 1.0f;
+}
+__device__ float synth_height_km(float px, float py, float pz, int octaves, int levels, uint32_t seed) {
+    float hkm = 0.0f, amp = 2.2f, fr = 2.0f;
+    for (int o = 0; o < octaves; o++) {
+        hkm += amp * vnoise3(px * fr + 17.3f, py * fr - 4.1f, pz * fr + 9.7f, seed + 101u * (uint32_t)o);
+        fr *= 2.0f; amp *= 0.56f;
+    }
+    float cell = 0.5f;
+    for (int l = 0; l < levels; l++) {
+        const float inv = 1.0f / cell;
+        const int cx = (int)floorf(px * inv), cy = (int)floorf(py * inv), cz = (int)floorf(pz * inv);
+        for (int dz = -1; dz <= 1; dz++)
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int ix = cx + dx, iy = cy + dy, iz = cz + dz;
+                    const uint32_t s2 = seed ^ (0x51ed27u * (uint32_t)(l + 1));
+                    if (hash01(ix, iy, iz, s2) > 0.55f) continue;
+                    float qx = ((float)ix + hash01(ix, iy, iz, s2 + 1u)) * cell;
+                    float qy = ((float)iy + hash01(ix, iy, iz, s2 + 2u)) * cell;
+                    float qz = ((float)iz + hash01(ix, iy, iz, s2 + 3u)) * cell;
+                    const float ql = sqrtf(qx * qx + qy * qy + qz * qz);
+                    if (fabsf(ql - 1.0f) > 0.5f * cell) continue;
+                    qx /= ql; qy /= ql; qz /= ql;
+                    const float rad = cell * (0.12f + 0.28f * hash01(ix, iy, iz, s2 + 4u));
+                    const float ex = px - qx, ey = py - qy, ez = pz - qz;
+                    const float tt = sqrtf(ex * ex + ey * ey + ez * ez) / rad;
+                    if (tt >= 1.4f) continue;
+                    const float rad_km = rad * 1737.4f;
+                    const float depth = fminf(0.4f * rad_km, 2.5f + 0.006f * rad_km);
+                    const float rim = 0.22f * depth;
+                    if (tt < 1.0f) hkm += -depth * (1.0f - tt * tt) + rim * tt * tt;
+                    else { const float e = (1.4f - tt) * 2.5f; hkm += rim * e * e; }
+                }
+        cell *= 0.5f;
+    }
+    return hkm;
+}
+__global__ void synth_ldem_kernel(int16_t* __restrict__ dst, int h, int w, int octaves, int levels, uint32_t seed) {
+    const int64_t n = (int64_t)h * w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / w), c = (int)(i % w);
+        const float lat = (0.5f - ((float)r + 0.5f) / (float)h) * 3.14159265f;
+        const float lon = (((float)c + 0.5f) / (float)w - 0.5f) * 6.2831853f;
+        const float cl = cosf(lat);
+        const float hk = synth_height_km(cl * sinf(lon), -cl * cosf(lon), sinf(lat), octaves, levels, seed);
+        float units = hk * 2000.0f;
+        units = fminf(fmaxf(units, -18200.0f), 21600.0f);
+        dst[i] = (int16_t)(int)rintf(units);
+    }
+}
+__global__ void synth_color_kernel(uint32_t* __restrict__ dst, int h, int w, uint32_t seed) {
+    const int64_t n = (int64_t)h * w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / w), c = (int)(i % w);
+        const float lat = (0.5f - ((float)r + 0.5f) / (float)h) * 3.14159265f;
+        const float lon = (((float)c + 0.5f) / (float)w - 0.5f) * 6.2831853f;
+        const float cl = cosf(lat);
+        const float px = cl * sinf(lon), py = -cl * cosf(lon), pz = sinf(lat);
+        float v = 0.0f, amp = 0.5f, fr = 1.5f;
+        for (int o = 0; o < 9; o++) {
+            v += amp * vnoise3(px * fr + 3.1f, py * fr + 7.7f, pz * fr - 2.9f, seed + 977u * (uint32_t)o);
+            fr *= 2.1f; amp *= 0.6f;
+        }
+        // source byte 0..255 -> the reference's albedo range 0.2 + 0.75 v/255, then ^gamma 2.2, as bytes
+        // (data_loader.py:261-287); small per-channel tint so the three channels differ.
+        const float sv = fminf(fmaxf(0.5f + 0.55f * v, 0.0f), 1.0f);
+        const float alb = 0.2f + 0.75f * sv;
+        const uint32_t R = (uint32_t)(255.0f * powf(alb, 2.2f));
+        const uint32_t G = (uint32_t)(255.0f * powf(alb * 0.985f, 2.2f));
+        const uint32_t B = (uint32_t)(255.0f * powf(alb * 0.955f, 2.2f));
+        dst[i] = R | (G << 8) | (B << 16) | 0xFF000000u;
+    }
+}
+
+__global__ void probe_atan2_kernel(const float* y, const float* x, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = atan2_poly(y[i], x[i]);
+}
+
+}  // namespace mrtx
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (called from mrtx_api.hip)
+extern "C++" {
+hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, hipStream_t st) {
+    const int subs = (f.tile_w >> 4) * (f.tile_h >> 4);
+    const int groups = (f.n_local_tiles + 7) / 8;
+    const dim3 grid((unsigned)(groups * subs * 8)), block(256);
+    if (grid.x == 0) return hipSuccess;
+#define MRTX_CASE(SV)                                                                          \
+    case SV:                                                                                   \
+        if (stats) hipLaunchKernelGGL((mrtx::render_kernel<SV, true>), grid, block, 0, st, f); \
+        else hipLaunchKernelGGL((mrtx::render_kernel<SV, false>), grid, block, 0, st, f);      \
+        break;
+    switch (S) {
+        MRTX_CASE(1) MRTX_CASE(2) MRTX_CASE(4) MRTX_CASE(8) MRTX_CASE(16) MRTX_CASE(32) MRTX_CASE(64)
+        default: return hipErrorInvalidValue;
+    }
+#undef MRTX_CASE
+    return hipGetLastError();
+}
+
+static inline unsigned grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t npix, uint32_t ns, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::resolve_linear_kernel, dim3(grid_for(npix)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(accum), reinterpret_cast<float4*>(out), npix, ns);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
+                                     float invg, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::resolve_rgba8_kernel, dim3(grid_for(npix)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(accum), out, npix, ns, expo, invg);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
+                            int tiles_x, int n_tiles, int rank, int world, int slots, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::pack_shard_kernel, dim3(grid_for((int64_t)slots * tw * th)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(accum), reinterpret_cast<const float4*>(hits),
+                       reinterpret_cast<float4*>(dst), W, H, tw, th, tiles_x, n_tiles, rank, world, slots);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
+                              int tiles_x, int n_tiles, int src_rank, int world, int slots, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::unpack_shard_kernel, dim3(grid_for((int64_t)slots * tw * th)), dim3(256), 0, st,
+                       reinterpret_cast<float4*>(accum), reinterpret_cast<float4*>(hits),
+                       reinterpret_cast<const float4*>(src), W, H, tw, th, tiles_x, n_tiles, src_rank, world, slots);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_ldem(const int16_t* src, float* dst, int h, int w, int d, unsigned int* max_bits,
+                            hipStream_t st) {
+    const int64_t n = (int64_t)h * w;
+    hipLaunchKernelGGL(mrtx::ldem_block_mean_kernel, dim3(grid_for(n)), dim3(256), 0, st, src, dst, h, w, d, max_bits);
+    hipLaunchKernelGGL(mrtx::scale_by_inv_kernel, dim3(grid_for(n)), dim3(256), 0, st, dst, n, max_bits);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_synth_ldem(int16_t* dst, int h, int w, uint32_t seed, hipStream_t st) {
+    int octaves = 1, levels = 1;
+    while ((8 << octaves) < w && octaves < 13) octaves++;
+    while ((64 << levels) < w && levels < 10) levels++;
+    hipLaunchKernelGGL(mrtx::synth_ldem_kernel, dim3(grid_for((int64_t)h * w)), dim3(256), 0, st, dst, h, w,
+                       octaves, levels, seed);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::synth_color_kernel, dim3(grid_for((int64_t)h * w)), dim3(256), 0, st, dst, h, w, seed);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_probe_atan2(const float* y, const float* x, float* out, int n, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::probe_atan2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, y, x, out, n);
+    return hipGetLastError();
+}
+}

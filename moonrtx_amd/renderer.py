@@ -1,0 +1,263 @@
+"""MoonRT: object wrapper over the C ABI of libmoonrt.so (include/moonrt.h).
+
+One instance == one `mrtx_ctx` == what the reference holds in `self.rt` (moon_renderer.py:571-575),
+minus the Tk window.  The PlotOptiX-named surface (set_data / set_displacement / setup_camera / ...)
+lives in moonrtx_amd/tkoptix.py and is a thin adapter over this class.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MrtxConfig, MrtxParams, MrtxStats, vec3
+
+
+class MoonRTError(RuntimeError):
+    pass
+
+
+class DeviceBuffer:
+    """A raw device allocation owned by the host side (inputs built on the GPU: synthetic DEMs...)."""
+
+    def __init__(self, nbytes, device=0):
+        self._lib = _lib.load()
+        self.device = int(device)
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        rc = self._lib.mrtx_dev_alloc(self.device, self.nbytes, C.byref(p))
+        if rc != 0 or not p.value:
+            raise MoonRTError(f"device allocation of {self.nbytes} bytes failed (code {rc})")
+        self.ptr = p.value
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("download larger than the buffer")
+        rc = self._lib.mrtx_dev_download(self.device, out.ctypes.data, self.ptr, out.nbytes)
+        if rc != 0:
+            raise MoonRTError(f"device download failed (code {rc})")
+        return out
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        if a.nbytes > self.nbytes:
+            raise ValueError("upload larger than the buffer")
+        rc = self._lib.mrtx_dev_upload(self.device, self.ptr, a.ctypes.data, a.nbytes)
+        if rc != 0:
+            raise MoonRTError(f"device upload failed (code {rc})")
+
+    def free(self):
+        if self.ptr:
+            self._lib.mrtx_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MoonRT:
+    def __init__(self, width, height, device=0, rank=0, world=1, tile=(32, 32)):
+        self._lib = _lib.load()
+        self.width, self.height = int(width), int(height)
+        self.rank, self.world = int(rank), int(world)
+        cfg = MrtxConfig(int(device), self.width, self.height, self.rank, self.world, int(tile[0]), int(tile[1]))
+        ctx = C.c_void_p()
+        rc = self._lib.mrtx_create(C.byref(cfg), C.byref(ctx))
+        self._ctx = ctx
+        if rc != 0:
+            msg = self._lib.mrtx_last_error(ctx).decode() if ctx.value else "invalid configuration"
+            if ctx.value:
+                self._lib.mrtx_destroy(ctx)
+            self._ctx = None
+            raise MoonRTError(f"mrtx_create failed ({rc}): {msg}")
+        self.params = MrtxParams()
+        self._lib.mrtx_default_params(C.byref(self.params))
+        self._keepalive = {}
+
+    # ---- plumbing
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MoonRTError(f"{what} failed ({rc}): {self._lib.mrtx_last_error(self._ctx).decode()}")
+
+    def close(self):
+        if self._ctx is not None:
+            self._lib.mrtx_destroy(self._ctx)
+            self._ctx = None
+            self._keepalive.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- resources
+    def upload_dem(self, elevation):
+        a = np.ascontiguousarray(elevation, np.float32)
+        if a.ndim != 2:
+            raise ValueError("elevation must be a 2-D float32 array")
+        self._check(self._lib.mrtx_upload_dem(self._ctx, a.ctypes.data, a.shape[0], a.shape[1]), "mrtx_upload_dem")
+        self._keepalive.pop("dem", None)
+
+    def bind_dem(self, buf, h, w):
+        self._check(self._lib.mrtx_bind_dem_device(self._ctx, buf.ptr, h, w), "mrtx_bind_dem_device")
+        self._keepalive["dem"] = buf
+
+    def upload_color(self, rgba):
+        if rgba is None:
+            self._check(self._lib.mrtx_upload_color(self._ctx, None, 0, 0), "mrtx_upload_color")
+            return
+        a = np.ascontiguousarray(rgba, np.uint8)
+        if a.ndim != 3 or a.shape[2] != 4:
+            raise ValueError("colour texture must be (h, w, 4) uint8")
+        self._check(self._lib.mrtx_upload_color(self._ctx, a.ctypes.data, a.shape[0], a.shape[1]), "mrtx_upload_color")
+        self._keepalive.pop("color", None)
+
+    def bind_color(self, buf, h, w):
+        self._check(self._lib.mrtx_bind_color_device(self._ctx, buf.ptr if buf else None, h, w), "mrtx_bind_color_device")
+        self._keepalive["color"] = buf
+
+    def upload_background(self, rgba):
+        if rgba is None:
+            self._check(self._lib.mrtx_upload_background(self._ctx, None, 0, 0), "mrtx_upload_background")
+            return
+        a = np.ascontiguousarray(rgba, np.uint8)
+        if a.ndim != 3 or a.shape[2] != 4:
+            raise ValueError("background must be (h, w, 4) uint8")
+        self._check(self._lib.mrtx_upload_background(self._ctx, a.ctypes.data, a.shape[0], a.shape[1]),
+                    "mrtx_upload_background")
+
+    # ---- scene state
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if k == "const_albedo":
+                self.params.const_albedo = (C.c_float * 3)(*[float(t) for t in v])
+            elif hasattr(self.params, k):
+                setattr(self.params, k, v)
+            else:
+                raise KeyError(f"unknown renderer parameter {k!r}")
+        self._check(self._lib.mrtx_set_params(self._ctx, C.byref(self.params)), "mrtx_set_params")
+
+    def set_camera(self, eye, target, up, vfov_deg):
+        self._check(self._lib.mrtx_set_camera(self._ctx, vec3(eye), vec3(target), vec3(up), float(vfov_deg)),
+                    "mrtx_set_camera")
+
+    def set_moon_frame(self, center, radius, u, v):
+        self._check(self._lib.mrtx_set_moon_frame(self._ctx, vec3(center), float(radius), vec3(u), vec3(v)),
+                    "mrtx_set_moon_frame")
+
+    def set_light(self, pos, radius, radiance):
+        self._check(self._lib.mrtx_set_light(self._ctx, vec3(pos), float(radius), float(radiance)), "mrtx_set_light")
+
+    def set_sun_disk(self, pos, radius, radiance):
+        self._check(self._lib.mrtx_set_sun_disk(self._ctx, vec3(pos), float(radius), float(radiance)),
+                    "mrtx_set_sun_disk")
+
+    def apply_scene(self, s):
+        """Push a moonrtx_amd.scene.SceneDesc (everything except textures)."""
+        self.set_params(scene_epsilon=s.scene_epsilon, marching_step=s.marching_step,
+                        marching_step_eps=s.marching_step_eps, tonemap_exposure=s.exposure,
+                        tonemap_gamma=s.gamma, spp_per_launch=s.spp_per_launch, max_spp=s.max_spp,
+                        seed=s.seed, const_albedo=s.const_albedo)
+        self.set_camera(s.eye, s.target, s.up, s.vfov_deg)
+        self.set_moon_frame(s.center, s.radius, s.u, s.v)
+        self.set_light(s.light_pos, s.light_radius, s.light_radiance)
+        self.set_sun_disk(s.sun_pos, s.sun_radius, s.sun_radiance)
+
+    # ---- rendering
+    def reset(self):
+        self._check(self._lib.mrtx_reset_accum(self._ctx), "mrtx_reset_accum")
+
+    def render(self, n_blocks=1):
+        st = MrtxStats()
+        self._check(self._lib.mrtx_render(self._ctx, int(n_blocks), C.byref(st)), "mrtx_render")
+        return {name: getattr(st, name) for name, _ in MrtxStats._fields_ if name != "reserved"}
+
+    def samples_done(self):
+        n = C.c_uint32()
+        self._check(self._lib.mrtx_samples_done(self._ctx, C.byref(n)), "mrtx_samples_done")
+        return n.value
+
+    def read_linear(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.mrtx_read_linear(self._ctx, out.ctypes.data), "mrtx_read_linear")
+        return out
+
+    def read_rgba8(self):
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        self._check(self._lib.mrtx_read_rgba8(self._ctx, out.ctypes.data), "mrtx_read_rgba8")
+        return out
+
+    def read_hits(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.mrtx_read_hits(self._ctx, out.ctypes.data), "mrtx_read_hits")
+        return out
+
+    # ---- multi-GPU exchange
+    def shard_bytes(self, rank=None):
+        n = C.c_uint64()
+        self._check(self._lib.mrtx_shard_bytes(self._ctx, self.rank if rank is None else rank, C.byref(n)),
+                    "mrtx_shard_bytes")
+        return n.value
+
+    def pack_shard(self, dev_ptr, stream=None):
+        self._check(self._lib.mrtx_pack_shard(self._ctx, dev_ptr, stream), "mrtx_pack_shard")
+
+    def unpack_shard(self, src_rank, dev_ptr, stream=None):
+        self._check(self._lib.mrtx_unpack_shard(self._ctx, int(src_rank), dev_ptr, stream), "mrtx_unpack_shard")
+
+    def device_ptr(self, which):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.mrtx_device_ptr(self._ctx, which, C.byref(p), C.byref(n)), "mrtx_device_ptr")
+        return p.value, n.value
+
+
+# ---- context-free device helpers ------------------------------------------------------------------
+def _err_call(fn, *args):
+    lib = _lib.load()
+    buf = C.create_string_buffer(256)
+    rc = getattr(lib, fn)(*args, buf, 256)
+    if rc != 0:
+        raise MoonRTError(f"{fn} failed ({rc}): {buf.value.decode()}")
+
+
+def synth_ldem(h, w, seed=0x4D525458, device=0):
+    """Seeded synthetic int16 LDEM-like source, generated on the device."""
+    buf = DeviceBuffer(h * w * 2, device)
+    _err_call("mrtx_synth_ldem", device, buf.ptr, h, w, seed & 0xFFFFFFFF)
+    return buf
+
+
+def synth_color(h, w, seed=0x4D525458, device=0):
+    buf = DeviceBuffer(h * w * 4, device)
+    _err_call("mrtx_synth_color", device, buf.ptr, h, w, seed & 0xFFFFFFFF)
+    return buf
+
+
+def dem_from_ldem(src_buf, h, w, downscale=1, device=0):
+    """Device restatement of load_elevation_data (data_loader.py:166-247).
+
+    `src_buf` holds the int16 (h*downscale, w*downscale) source; returns (float32 DeviceBuffer (h, w),
+    radius_scale)."""
+    lib = _lib.load()
+    dst = DeviceBuffer(h * w * 4, device)
+    scale = C.c_float()
+    buf = C.create_string_buffer(256)
+    rc = lib.mrtx_dem_from_ldem(device, src_buf.ptr, h, w, downscale, dst.ptr, C.byref(scale), buf, 256)
+    if rc != 0:
+        raise MoonRTError(f"mrtx_dem_from_ldem failed ({rc}): {buf.value.decode()}")
+    return dst, float(scale.value)
+
+
+def probe_atan2(y, x, device=0):
+    lib = _lib.load()
+    y = np.ascontiguousarray(y, np.float32).ravel()
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    out = np.empty_like(y)
+    rc = lib.mrtx_probe_atan2(device, y.ctypes.data, x.ctypes.data, out.ctypes.data, y.size)
+    if rc != 0:
+        raise MoonRTError(f"mrtx_probe_atan2 failed ({rc})")
+    return out

@@ -1,0 +1,593 @@
+/*
+ * mrtx_oracle.c -- CPU oracle for the MoonRTX hot path (TEST INFRASTRUCTURE, NOT PRODUCT).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * library.  The shipped renderer (moonrtx_amd/, libmoonrt.so) never links, imports or calls it.
+ *
+ * PARITY UNPINNED against PlotOptiX: the reference delegates every pixel to the closed third-party
+ * package plotoptix>=0.19.2 (requirements.txt:3; call sites moon_renderer.py:571-650, :854-871),
+ * which is not in /root/reference, not installed and not fetchable, and the reference ships no
+ * tests and no golden frames (the images/ jpgs are git-LFS pointers).  What IS pinned, by golden
+ * vectors captured from the reference modules that import here (tests/golden/, made by
+ * tests/golden/make_golden.py):
+ *   - the DEM <-> sphere mapping and bilinear convention  (renderer_navigation.py:575-593)
+ *   - the body frame / hit-buffer convention              (renderer_navigation.py:43-57, :452-492)
+ * Everything else restates the scene the reference *describes* through its renderer calls:
+ *   D1 pinhole camera, vertical fov            moon_renderer.py:627-635, renderer_navigation.py:330-332
+ *   D2 displaced-sphere height-field march     moon_renderer.py:620-624, :586-588 (marching_step,
+ *      marching_step_eps, scene_epsilon), surface inside the radius-R sphere (data_loader.py:240-242)
+ *   D3 bilinear equirect DEM fetch             renderer_navigation.py:575-593
+ *   D4 Lambert x RGBA8 colour texture          moon_renderer.py:613-617
+ *   D5 spherical light, one shadow ray/sample  moon_renderer.py:640-641, :859-860, :65-71, :89-93
+ *   D7 environment texel / black on a miss     moon_renderer.py:604-609
+ *   D8 flat emissive Sun-disk sphere           moon_renderer.py:647-650
+ *   D9 accumulation (running mean, linear)     moon_renderer.py:578
+ *   D10 hit-position buffer                    moon_renderer.py:1138, renderer_navigation.py:195-203
+ *
+ * The arithmetic below is the SPEC: float32 with explicit fmaf, float64 for
+ * the per-ray sphere entry, own polynomial atan/sin/cos (no libm transcendental on the per-sample
+ * path), counter-based integer RNG.  Compile with -ffp-contract=off.  The HIP kernels follow the
+ * same spec independently; tests require bit-exact agreement.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct OrcScene {
+    int32_t width, height;
+    float scene_epsilon, marching_step, marching_step_eps;
+    uint32_t spp_per_block, seed;
+    float const_albedo[3];
+    double eye[3], target[3], up[3], vfov_deg;
+    double center[3], radius, u[3], v[3];
+    double light_pos[3], light_radius, light_radiance;
+    double sun_pos[3], sun_radius, sun_radiance;
+    const float* dem;
+    int32_t dem_h, dem_w;
+    const uint8_t* color;
+    int32_t color_h, color_w;
+    const uint8_t* bg;
+    int32_t bg_h, bg_w;
+} OrcScene;
+
+/* indices of the stats array */
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_N };
+
+/* ------------------------------------------------------------------ spec constants */
+#define PI_D 3.14159265358979323846
+static const float PI_F = 3.14159274101257324f;
+static const float HALF_PI_F = 1.57079637050628662f;
+/* atan(q) ~= q * P(q^2) on [0,1], |err| <= 1.3e-7 */
+static const float AT0 = 0.9999993443489075f, AT1 = -0.33329859375953674f, AT2 = 0.19946560263633728f,
+                   AT3 = -0.1390860229730606f, AT4 = 0.0964212492108345f, AT5 = -0.05591127648949623f,
+                   AT6 = 0.02186218835413456f, AT7 = -0.004054343327879906f;
+/* sin / cos on [0, pi/2] */
+static const float SN0 = 1.0f, SN1 = -0.16666647791862488f, SN2 = 0.008332899771630764f,
+                   SN3 = -0.00019800894369836897f, SN4 = 2.590481244624243e-06f;
+static const float CS0 = 0.9999999403953552f, CS1 = -0.4999990463256836f, CS2 = 0.04166358336806297f,
+                   CS3 = -0.001385370153002441f, CS4 = 2.3153859729063697e-05f;
+
+float orc_atan2f(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    float q = (mx == 0.0f) ? 0.0f : mn / mx;
+    float s = q * q;
+    float p = AT7;
+    p = fmaf(p, s, AT6);
+    p = fmaf(p, s, AT5);
+    p = fmaf(p, s, AT4);
+    p = fmaf(p, s, AT3);
+    p = fmaf(p, s, AT2);
+    p = fmaf(p, s, AT1);
+    p = fmaf(p, s, AT0);
+    float r = p * q;
+    if (ay > ax) r = HALF_PI_F - r;
+    if (x < 0.0f) r = PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+static inline void sincos_quadrant(float u, float* cs, float* sn) {
+    /* angle = 2*pi*u, u in [0,1): quadrant + polynomial on [0, pi/2) */
+    float t4 = u * 4.0f;
+    float qf = floorf(t4);
+    float a = (t4 - qf) * HALF_PI_F;
+    float a2 = a * a;
+    float sp = SN4;
+    sp = fmaf(sp, a2, SN3);
+    sp = fmaf(sp, a2, SN2);
+    sp = fmaf(sp, a2, SN1);
+    sp = fmaf(sp, a2, SN0);
+    float s1 = sp * a;
+    float cp = CS4;
+    cp = fmaf(cp, a2, CS3);
+    cp = fmaf(cp, a2, CS2);
+    cp = fmaf(cp, a2, CS1);
+    cp = fmaf(cp, a2, CS0);
+    float c1 = cp;
+    int qi = (int)qf;
+    if (qi == 0) { *cs = c1; *sn = s1; }
+    else if (qi == 1) { *cs = -s1; *sn = c1; }
+    else if (qi == 2) { *cs = -c1; *sn = -s1; }
+    else { *cs = s1; *sn = -c1; }
+}
+
+static inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+static inline float u01(uint32_t key, uint32_t dim) {
+    uint32_t r = mix32(key + (dim + 1u) * 0x9E3779B9u);
+    return (float)(r >> 8) * 5.9604644775390625e-08f; /* 2^-24 */
+}
+
+/* ------------------------------------------------------------------ equirect grid */
+typedef struct Grid {
+    int32_t h, w;
+    float row_scale, row_off, col_scale, col_off, wf;
+} Grid;
+
+static void grid_init(Grid* g, int32_t h, int32_t w) {
+    g->h = h; g->w = w;
+    g->row_scale = (float)(-(double)h / PI_D);
+    g->row_off = (float)(0.5 * (double)h - 0.5);
+    g->col_scale = (float)((double)w / (2.0 * PI_D));
+    g->col_off = (float)(0.5 * (double)w - 0.5);
+    g->wf = (float)w;
+}
+
+typedef struct Tap { int64_t i00, i01, i10, i11; float fr, fc; } Tap;
+
+/* texel coordinates -> the four taps; rows clamp, columns wrap (renderer_navigation.py:581-588) */
+static inline void grid_tap(const Grid* g, float rowf, float colf, Tap* t) {
+    if (colf < 0.0f) colf += g->wf;
+    if (colf >= g->wf) colf -= g->wf;
+    float rfl = floorf(rowf);
+    int32_t r0 = (int32_t)rfl;
+    r0 = r0 < 0 ? 0 : (r0 > g->h - 2 ? g->h - 2 : r0);
+    float fr = rowf - (float)r0;
+    fr = fr < 0.0f ? 0.0f : (fr > 1.0f ? 1.0f : fr);
+    float cfl = floorf(colf);
+    int32_t c0 = (int32_t)cfl;
+    float fc = colf - cfl;
+    if (c0 >= g->w) c0 -= g->w;
+    int32_t c1 = c0 + 1;
+    if (c1 >= g->w) c1 = 0;
+    int64_t b0 = (int64_t)r0 * g->w, b1 = b0 + g->w;
+    t->i00 = b0 + c0; t->i01 = b0 + c1; t->i10 = b1 + c0; t->i11 = b1 + c1;
+    t->fr = fr; t->fc = fc;
+}
+static inline void grid_rc(const Grid* g, float lat, float lon, float* rowf, float* colf) {
+    *rowf = fmaf(lat, g->row_scale, g->row_off);
+    *colf = fmaf(lon, g->col_scale, g->col_off);
+}
+static inline float lerp2(float e00, float e01, float e10, float e11, float fr, float fc) {
+    float top = fmaf(fc, e01 - e00, e00);
+    float bot = fmaf(fc, e11 - e10, e10);
+    return fmaf(fr, bot - top, top);
+}
+static inline float dem_at(const float* dem, const Grid* g, float rowf, float colf) {
+    Tap t;
+    grid_tap(g, rowf, colf, &t);
+    return lerp2(dem[t.i00], dem[t.i01], dem[t.i10], dem[t.i11], t.fr, t.fc);
+}
+
+/* bilinear DEM value at (lat, lon) in radians: the spec's D(lat, lon).  Exposed so tests can pin
+ * it to NavigationMixin.get_elevation_m golden vectors. */
+float orc_dem_bilinear(const float* dem, int32_t h, int32_t w, float lat, float lon) {
+    Grid g; grid_init(&g, h, w);
+    float rowf, colf; grid_rc(&g, lat, lon, &rowf, &colf);
+    return dem_at(dem, &g, rowf, colf);
+}
+
+/* ------------------------------------------------------------------ derived frame constants */
+typedef struct Frame {
+    float Wd[3], Ux[3], Vy[3], two_over_w, two_over_h;
+    double oc[3], cq, M[3][3];
+    float Mf[3][3], centerf[3], eyef[3];
+    float Rf, R2f;
+    float Lb[3], rL2, rad2;
+    int sun_on; float sc[3], sun_cq, sun_rad;
+    float step, eps; int nbis, kmax;
+    float dlat_scale, dlon_scale;
+    Grid gd, gc, gb;
+    float bg_row_scale, bg_row_off, bg_col_scale, bg_col_off;
+    uint32_t key0;
+} Frame;
+
+static void normalize3(double v[3]) {
+    double l = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    v[0] /= l; v[1] /= l; v[2] /= l;
+}
+static void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+static void frame_init(Frame* f, const OrcScene* s) {
+    int i, j;
+    double wv[3], uv[3], vv[3];
+    for (i = 0; i < 3; i++) wv[i] = s->target[i] - s->eye[i];
+    normalize3(wv);
+    cross3(wv, s->up, uv); normalize3(uv);
+    cross3(uv, wv, vv);
+    double th = tan(s->vfov_deg * PI_D / 360.0);
+    double aspect = (double)s->width / (double)s->height;
+    for (i = 0; i < 3; i++) {
+        f->Wd[i] = (float)wv[i];
+        f->Ux[i] = (float)(uv[i] * (th * aspect));
+        f->Vy[i] = (float)(vv[i] * th);
+        f->oc[i] = s->eye[i] - s->center[i];
+        f->centerf[i] = (float)s->center[i];
+        f->eyef[i] = (float)s->eye[i];
+    }
+    f->two_over_w = (float)(2.0 / (double)s->width);
+    f->two_over_h = (float)(2.0 / (double)s->height);
+    f->cq = ((f->oc[0] * f->oc[0] + f->oc[1] * f->oc[1]) + f->oc[2] * f->oc[2]) - s->radius * s->radius;
+    /* moon frame: rows = (east 90, lon 0, north) */
+    double ez[3], v0[3], ex[3];
+    for (i = 0; i < 3; i++) ez[i] = s->u[i];
+    normalize3(ez);
+    double dp = (s->v[0] * ez[0] + s->v[1] * ez[1]) + s->v[2] * ez[2];
+    for (i = 0; i < 3; i++) v0[i] = s->v[i] - dp * ez[i];
+    normalize3(v0);
+    cross3(ez, v0, ex);
+    for (j = 0; j < 3; j++) { f->M[0][j] = ex[j]; f->M[1][j] = v0[j]; f->M[2][j] = ez[j]; }
+    for (i = 0; i < 3; i++) for (j = 0; j < 3; j++) f->Mf[i][j] = (float)f->M[i][j];
+    f->Rf = (float)s->radius;
+    f->R2f = f->Rf * f->Rf;
+    double lr[3];
+    for (i = 0; i < 3; i++) lr[i] = s->light_pos[i] - s->center[i];
+    for (i = 0; i < 3; i++) f->Lb[i] = (float)((f->M[i][0] * lr[0] + f->M[i][1] * lr[1]) + f->M[i][2] * lr[2]);
+    f->rL2 = (float)(s->light_radius * s->light_radius);
+    f->rad2 = (float)(2.0 * s->light_radiance);
+    f->sun_on = s->sun_radius > 0.0;
+    double sr[3];
+    for (i = 0; i < 3; i++) { sr[i] = s->sun_pos[i] - s->eye[i]; f->sc[i] = (float)sr[i]; }
+    f->sun_cq = (float)(((sr[0] * sr[0] + sr[1] * sr[1]) + sr[2] * sr[2]) - s->sun_radius * s->sun_radius);
+    f->sun_rad = (float)s->sun_radiance;
+    f->step = s->marching_step;
+    f->eps = s->marching_step_eps;
+    f->nbis = 0;
+    { double wdt = (double)f->step; while (wdt > (double)f->eps && f->nbis < 24) { wdt *= 0.5; f->nbis++; } }
+    f->kmax = (int)(2.0 * s->radius / (double)f->step) + 8;
+    grid_init(&f->gd, s->dem_h, s->dem_w);
+    f->dlat_scale = (float)((double)s->dem_h / (2.0 * PI_D));
+    f->dlon_scale = (float)((double)s->dem_w / (4.0 * PI_D));
+    if (s->color) grid_init(&f->gc, s->color_h, s->color_w);
+    if (s->bg) {
+        f->bg_row_scale = (float)(-(double)s->bg_h / PI_D);
+        f->bg_row_off = (float)(0.5 * (double)s->bg_h);
+        f->bg_col_scale = (float)((double)s->bg_w / (2.0 * PI_D));
+        f->bg_col_off = (float)(0.5 * (double)s->bg_w);
+    }
+    f->key0 = mix32(s->seed ^ 0x9E3779B9u);
+}
+
+/* exposes the float frame constants for host-logic parity tests (46 floats) */
+void orc_frame_floats(const OrcScene* s, float* out) {
+    Frame f; frame_init(&f, s);
+    int k = 0, i, j;
+    for (i = 0; i < 3; i++) out[k++] = f.Wd[i];
+    for (i = 0; i < 3; i++) out[k++] = f.Ux[i];
+    for (i = 0; i < 3; i++) out[k++] = f.Vy[i];
+    for (i = 0; i < 3; i++) for (j = 0; j < 3; j++) out[k++] = f.Mf[i][j];
+    for (i = 0; i < 3; i++) out[k++] = f.Lb[i];
+    out[k++] = f.rL2; out[k++] = f.rad2; out[k++] = f.R2f;
+    for (i = 0; i < 3; i++) out[k++] = f.sc[i];
+    out[k++] = f.sun_cq; out[k++] = (float)f.nbis; out[k++] = (float)f.kmax;
+    out[k++] = f.gd.row_scale; out[k++] = f.gd.row_off; out[k++] = f.gd.col_scale; out[k++] = f.gd.col_off;
+    out[k++] = f.dlat_scale; out[k++] = f.dlon_scale;
+    out[k++] = (float)f.cq; out[k++] = f.two_over_w; out[k++] = f.two_over_h;
+}
+
+/* ------------------------------------------------------------------ the march */
+static inline int below_surface(const OrcScene* s, const Frame* f, float pa, float pb, float pc,
+                                uint64_t* st) {
+    float rho2 = fmaf(pb, pb, pa * pa);
+    float r2 = fmaf(pc, pc, rho2);
+    float rho = sqrtf(rho2);
+    float lat = orc_atan2f(pc, rho);
+    float lon = orc_atan2f(pa, pb);
+    float rowf, colf;
+    grid_rc(&f->gd, lat, lon, &rowf, &colf);
+    float d = dem_at(s->dem, &f->gd, rowf, colf);
+    st[ST_HEIGHT]++;
+    float surf = f->Rf * d;
+    return r2 <= surf * surf;
+}
+
+typedef struct Sample { float c[3]; float hitflag; float hit[4]; } Sample;
+
+static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32_t gs, Sample* o,
+                         uint64_t* st) {
+    uint32_t pix = (uint32_t)y * (uint32_t)s->width + (uint32_t)x;
+    uint32_t kp = mix32(pix + f->key0);
+    uint32_t ks = mix32(kp ^ (gs * 0x85EBCA6Bu + 1u));
+    float u0 = u01(ks, 0), u1 = u01(ks, 1), u2 = u01(ks, 2), u3 = u01(ks, 3);
+    o->c[0] = o->c[1] = o->c[2] = 0.0f; o->hitflag = 0.0f;
+    o->hit[0] = o->hit[1] = o->hit[2] = o->hit[3] = 0.0f;
+    st[ST_PRIMARY]++;
+
+    float fx = (float)x + u0, fy = (float)y + u1;
+    float sx = fmaf(fx, f->two_over_w, -1.0f);
+    float sy = fmaf(-fy, f->two_over_h, 1.0f);
+    float dx = fmaf(sy, f->Vy[0], fmaf(sx, f->Ux[0], f->Wd[0]));
+    float dy = fmaf(sy, f->Vy[1], fmaf(sx, f->Ux[1], f->Wd[1]));
+    float dz = fmaf(sy, f->Vy[2], fmaf(sx, f->Ux[2], f->Wd[2]));
+    float len = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    dx = dx / len; dy = dy / len; dz = dz / len;
+
+    /* float64 entry into the bounding sphere */
+    double Dx = (double)dx, Dy = (double)dy, Dz = (double)dz;
+    double a = (Dx * Dx + Dy * Dy) + Dz * Dz;
+    double b = (f->oc[0] * Dx + f->oc[1] * Dy) + f->oc[2] * Dz;
+    double disc = b * b - a * f->cq;
+    int on_sphere = 0;
+    double t0 = 0.0, t1 = 0.0;
+    if (disc > 0.0) {
+        double sq = sqrt(disc);
+        t0 = (-b - sq) / a;
+        t1 = (-b + sq) / a;
+        if (t1 > 0.0) { on_sphere = 1; if (t0 < 0.0) t0 = 0.0; }
+    }
+    int hit = 0;
+    float pa = 0, pb = 0, pc = 0, da = 0, db = 0, dc = 0, lo = 0.0f;
+    if (on_sphere) {
+        double pe0 = f->oc[0] + t0 * Dx, pe1 = f->oc[1] + t0 * Dy, pe2 = f->oc[2] + t0 * Dz;
+        pa = (float)((f->M[0][0] * pe0 + f->M[0][1] * pe1) + f->M[0][2] * pe2);
+        pb = (float)((f->M[1][0] * pe0 + f->M[1][1] * pe1) + f->M[1][2] * pe2);
+        pc = (float)((f->M[2][0] * pe0 + f->M[2][1] * pe1) + f->M[2][2] * pe2);
+        da = (float)((f->M[0][0] * Dx + f->M[0][1] * Dy) + f->M[0][2] * Dz);
+        db = (float)((f->M[1][0] * Dx + f->M[1][1] * Dy) + f->M[1][2] * Dz);
+        dc = (float)((f->M[2][0] * Dx + f->M[2][1] * Dy) + f->M[2][2] * Dz);
+        float smax = (float)(t1 - t0);
+        float hi = 0.0f;
+        int k;
+        for (k = 1; k <= f->kmax; k++) {
+            float sk = (float)k * f->step;
+            if (sk > smax) break;
+            if (below_surface(s, f, fmaf(sk, da, pa), fmaf(sk, db, pb), fmaf(sk, dc, pc), st)) {
+                hit = 1; hi = sk; lo = (float)(k - 1) * f->step;
+                break;
+            }
+        }
+        if (hit) {
+            int i;
+            for (i = 0; i < f->nbis; i++) {
+                float mid = 0.5f * (lo + hi);
+                if (below_surface(s, f, fmaf(mid, da, pa), fmaf(mid, db, pb), fmaf(mid, dc, pc), st)) hi = mid;
+                else lo = mid;
+            }
+        }
+    }
+
+    if (!hit) {
+        /* D8 Sun disk, then D7 environment */
+        if (f->sun_on) {
+            float bq = fmaf(f->sc[2], dz, fmaf(f->sc[1], dy, f->sc[0] * dx));
+            float dq = fmaf(bq, bq, -f->sun_cq);
+            if (bq > 0.0f && dq > 0.0f) {
+                float t = bq - sqrtf(dq);
+                o->c[0] = o->c[1] = o->c[2] = f->sun_rad;
+                o->hitflag = 1.0f;
+                o->hit[0] = fmaf(t, dx, f->eyef[0]);
+                o->hit[1] = fmaf(t, dy, f->eyef[1]);
+                o->hit[2] = fmaf(t, dz, f->eyef[2]);
+                o->hit[3] = t;
+                return;
+            }
+        }
+        if (s->bg) {
+            float rho = sqrtf(fmaf(dy, dy, dx * dx));
+            float el = orc_atan2f(dz, rho);
+            float az = orc_atan2f(dx, dy);
+            float rowf = fmaf(el, f->bg_row_scale, f->bg_row_off);
+            float colf = fmaf(az, f->bg_col_scale, f->bg_col_off);
+            int r = (int)floorf(rowf), c = (int)floorf(colf);
+            r = r < 0 ? 0 : (r > s->bg_h - 1 ? s->bg_h - 1 : r);
+            if (c >= s->bg_w) c -= s->bg_w;
+            if (c < 0) c = 0;
+            const uint8_t* px = s->bg + 4 * ((int64_t)r * s->bg_w + c);
+            o->c[0] = (float)px[0] / 255.0f;
+            o->c[1] = (float)px[1] / 255.0f;
+            o->c[2] = (float)px[2] / 255.0f;
+            st[ST_BG]++;
+        }
+        return;
+    }
+
+    /* ---- hit: position, normal, albedo */
+    st[ST_HITS]++;
+    float ha = fmaf(lo, da, pa), hb = fmaf(lo, db, pb), hc = fmaf(lo, dc, pc);
+    float rho2 = fmaf(hb, hb, ha * ha);
+    float r2 = fmaf(hc, hc, rho2);
+    float rho = sqrtf(rho2);
+    float r = sqrtf(r2);
+    float lat = orc_atan2f(hc, rho);
+    float lon = orc_atan2f(ha, hb);
+    float rowf, colf;
+    grid_rc(&f->gd, lat, lon, &rowf, &colf);
+    float dn = dem_at(s->dem, &f->gd, rowf - 1.0f, colf);
+    float ds = dem_at(s->dem, &f->gd, rowf + 1.0f, colf);
+    float de = dem_at(s->dem, &f->gd, rowf, colf + 1.0f);
+    float dw = dem_at(s->dem, &f->gd, rowf, colf - 1.0f);
+    st[ST_HEIGHT] += 4;
+    float dlat = (dn - ds) * f->dlat_scale;
+    float dlon = (de - dw) * f->dlon_scale;
+    float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
+    float inv_r = 1.0f / r, inv_rho = 1.0f / rhoc;
+    float sphi = hc * inv_r, cphi = rhoc * inv_r;
+    float slam = ha * inv_rho, clam = hb * inv_rho;
+    float glat = (f->Rf * inv_r) * dlat;
+    float glon = (f->Rf * inv_rho) * dlon;
+    float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
+    float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
+    float nc = fmaf(-glat, cphi, hc * inv_r);
+    float nl = sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
+    na = na / nl; nb = nb / nl; nc = nc / nl;
+
+    float alb[3];
+    if (s->color) {
+        float rc, cc; Tap t; int ch;
+        grid_rc(&f->gc, lat, lon, &rc, &cc);
+        grid_tap(&f->gc, rc, cc, &t);
+        for (ch = 0; ch < 3; ch++) {
+            float v = lerp2((float)s->color[4 * t.i00 + ch], (float)s->color[4 * t.i01 + ch],
+                            (float)s->color[4 * t.i10 + ch], (float)s->color[4 * t.i11 + ch], t.fr, t.fc);
+            alb[ch] = v / 255.0f;
+        }
+        st[ST_COLOUR]++;
+    } else {
+        alb[0] = s->const_albedo[0]; alb[1] = s->const_albedo[1]; alb[2] = s->const_albedo[2];
+    }
+
+    o->hitflag = 1.0f;
+    o->hit[0] = f->centerf[0] + fmaf(hc, f->Mf[2][0], fmaf(hb, f->Mf[1][0], ha * f->Mf[0][0]));
+    o->hit[1] = f->centerf[1] + fmaf(hc, f->Mf[2][1], fmaf(hb, f->Mf[1][1], ha * f->Mf[0][1]));
+    o->hit[2] = f->centerf[2] + fmaf(hc, f->Mf[2][2], fmaf(hb, f->Mf[1][2], ha * f->Mf[0][2]));
+    o->hit[3] = (float)t0 + lo;
+
+    /* ---- D5: one sample of the spherical light */
+    float eps = s->scene_epsilon;
+    float oa = fmaf(eps, na, ha), ob = fmaf(eps, nb, hb), occ = fmaf(eps, nc, hc);
+    float ta = f->Lb[0] - oa, tb = f->Lb[1] - ob, tc = f->Lb[2] - occ;
+    float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
+    float dist = sqrtf(d2);
+    float la = ta / dist, lb = tb / dist, lc = tc / dist;
+    float sin2 = f->rL2 / d2;
+    if (sin2 > 1.0f) sin2 = 1.0f;
+    float cosmax = sqrtf(1.0f - sin2);
+    float omc = sin2 / (1.0f + cosmax);
+    float av = u2 * omc;
+    float cost = 1.0f - av;
+    float sint = sqrtf(av * (2.0f - av));
+    float cph, sph;
+    sincos_quadrant(u3, &cph, &sph);
+    float sg = lc >= 0.0f ? 1.0f : -1.0f;
+    float aa = -1.0f / (sg + lc);
+    float bb = (la * lb) * aa;
+    float b1a = fmaf(sg, (la * la) * aa, 1.0f), b1b = sg * bb, b1c = -sg * la;
+    float b2a = bb, b2b = fmaf(lb * lb, aa, sg), b2c = -lb;
+    float ca = sint * cph, sa = sint * sph;
+    float wa = fmaf(cost, la, fmaf(sa, b2a, ca * b1a));
+    float wb = fmaf(cost, lb, fmaf(sa, b2b, ca * b1b));
+    float wc = fmaf(cost, lc, fmaf(sa, b2c, ca * b1c));
+    float cosi = fmaf(nc, wc, fmaf(nb, wb, na * wa));
+    if (!(cosi > 0.0f)) return;
+
+    st[ST_SHADOW]++;
+    int lit = 1, k;
+    for (k = 1; k <= f->kmax; k++) {
+        float sk = (float)k * f->step;
+        float qa = fmaf(sk, wa, oa), qb = fmaf(sk, wb, ob), qc = fmaf(sk, wc, occ);
+        float q2 = fmaf(qc, qc, fmaf(qb, qb, qa * qa));
+        if (q2 > f->R2f) break;
+        if (below_surface(s, f, qa, qb, qc, st)) { lit = 0; break; }
+    }
+    if (!lit) return;
+    float wgt = (f->rad2 * omc) * cosi;
+    o->c[0] = alb[0] * wgt; o->c[1] = alb[1] * wgt; o->c[2] = alb[2] * wgt;
+}
+
+/* Render n_blocks accumulation blocks of spp_per_block samples for pixels [x0,x1) x [y0,y1).
+ * accum (W*H*4, in/out): running sums (r, g, b, hit-coverage).  hits (W*H*4, out): sample 0 of the
+ * last block.  stats: ST_N counters, added to.  first_block = number of blocks already accumulated. */
+int orc_render(const OrcScene* s, int x0, int y0, int x1, int y1, uint32_t first_block, uint32_t n_blocks,
+               float* accum, float* hits, uint64_t* stats) {
+    Frame f;
+    uint32_t S = s->spp_per_block;
+    if (S == 0 || S > 64 || (S & (S - 1)) != 0) return -1;
+    if (!s->dem || s->dem_h < 2 || s->dem_w < 2) return -1;
+    frame_init(&f, s);
+    int y;
+    uint64_t tot[ST_N];
+    memset(tot, 0, sizeof tot);
+#pragma omp parallel
+    {
+        uint64_t st[ST_N];
+        memset(st, 0, sizeof st);
+#pragma omp for schedule(dynamic, 1)
+        for (y = y0; y < y1; y++) {
+            int x;
+            for (x = x0; x < x1; x++) {
+                float* acc = accum + 4 * ((int64_t)y * s->width + x);
+                float sum[4] = { acc[0], acc[1], acc[2], acc[3] };
+                uint32_t blk;
+                for (blk = 0; blk < n_blocks; blk++) {
+                    float v[64][4];
+                    uint32_t i, stride;
+                    for (i = 0; i < S; i++) {
+                        Sample smp;
+                        trace_sample(s, &f, x, y, (first_block + blk) * S + i, &smp, st);
+                        v[i][0] = smp.c[0]; v[i][1] = smp.c[1]; v[i][2] = smp.c[2]; v[i][3] = smp.hitflag;
+                        if (i == 0 && blk == n_blocks - 1) {
+                            float* hp = hits + 4 * ((int64_t)y * s->width + x);
+                            hp[0] = smp.hit[0]; hp[1] = smp.hit[1]; hp[2] = smp.hit[2]; hp[3] = smp.hit[3];
+                        }
+                    }
+                    /* pairwise tree: the order an xor-butterfly over the lanes produces */
+                    for (stride = 1; stride < S; stride *= 2)
+                        for (i = 0; i + stride < S; i += 2 * stride) {
+                            v[i][0] += v[i + stride][0]; v[i][1] += v[i + stride][1];
+                            v[i][2] += v[i + stride][2]; v[i][3] += v[i + stride][3];
+                        }
+                    sum[0] += v[0][0]; sum[1] += v[0][1]; sum[2] += v[0][2]; sum[3] += v[0][3];
+                }
+                acc[0] = sum[0]; acc[1] = sum[1]; acc[2] = sum[2]; acc[3] = sum[3];
+            }
+        }
+        int i;
+#pragma omp critical
+        for (i = 0; i < ST_N; i++) tot[i] += st[i];
+    }
+    if (stats) { int i; for (i = 0; i < ST_N; i++) stats[i] += tot[i]; }
+    return 0;
+}
+
+/* linear = accum / n  (the resolve step of the spec) */
+void orc_resolve_linear(const float* accum, int64_t npix, uint32_t n_samples, float* out) {
+    int64_t i;
+    float n = (float)n_samples;
+    for (i = 0; i < 4 * npix; i++) out[i] = n_samples ? accum[i] / n : 0.0f;
+}
+
+/* data_loader.py:166-247 restated: int16 LDEM (h*d, w*d) -> float32 (h, w) displacement factors.
+ * Stage 1 (axis 4): exact integer sum of d int16 as float32, / d.  Stage 2 (axis 2): sequential
+ * float32 sum over the d rows, / d.  Then * (0.5/1737400), + 1, / max. */
+float orc_dem_from_ldem(const int16_t* src, int32_t h, int32_t w, int32_t d, float* dst) {
+    const float scale = (float)(0.5 / 1737400.0);
+    int64_t W = (int64_t)w * d;
+    float mx = -INFINITY;
+    int32_t r, c, i, j;
+    for (r = 0; r < h; r++)
+        for (c = 0; c < w; c++) {
+            float v;
+            if (d == 1) {
+                v = (float)src[(int64_t)r * W + c] * scale;
+            } else {
+                float acc2 = 0.0f;
+                for (i = 0; i < d; i++) {
+                    const int16_t* p = src + ((int64_t)r * d + i) * W + (int64_t)c * d;
+                    float acc = 0.0f;
+                    for (j = 0; j < d; j++) acc += (float)p[j];
+                    acc = acc / (float)d;
+                    acc2 = (i == 0) ? acc : acc2 + acc;
+                }
+                v = (acc2 / (float)d) * scale;
+            }
+            v += 1.0f;
+            dst[(int64_t)r * w + c] = v;
+            if (v > mx) mx = v;
+        }
+    for (r = 0; r < h; r++)
+        for (c = 0; c < w; c++) dst[(int64_t)r * w + c] /= mx;
+    return mx;
+}
+
+int orc_sizeof_scene(void) { return (int)sizeof(OrcScene); }

@@ -1,0 +1,42 @@
+"""Shared helpers for the parity tests: run the same scene through the HIP path and the oracle."""
+import numpy as np
+
+from oracle import orc
+from moonrtx_amd.renderer import MoonRT
+
+STAT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches",
+             "background_fetches")
+
+
+def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, tile=(32, 32)):
+    rt = MoonRT(scene.width, scene.height, rank=rank, world=world, tile=tile)
+    try:
+        rt.upload_dem(dem)
+        rt.upload_color(color)
+        rt.upload_background(bg)
+        rt.apply_scene(scene)
+        stats = {k: 0 for k in STAT_KEYS}
+        for nb in blocks:
+            st = rt.render(nb)
+            for k in STAT_KEYS:
+                stats[k] += st[k]
+        return rt.read_linear(), rt.read_hits(), stats, rt.read_rgba8()
+    finally:
+        rt.close()
+
+
+def render_oracle(scene, dem, color=None, bg=None, blocks=(1,), region=None):
+    o = orc.Oracle(scene, dem, color, bg)
+    for nb in blocks:
+        st = o.render(nb, region)
+    return o.linear(), o.hits.copy(), st
+
+
+def assert_bit_equal(a, b, what):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    same = a.view(np.uint32) == b.view(np.uint32)
+    if not same.all():
+        bad = np.argwhere(~same)
+        diff = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} values differ bitwise; max |diff| = {diff.max():.3e}; "
+                             f"first at {tuple(bad[0])}: {a[tuple(bad[0])]!r} vs {b[tuple(bad[0])]!r}")

@@ -1,0 +1,158 @@
+"""HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Bar: bit-exact linear radiance, hit buffer and sample counters (the north star asks for
+L_inf < 2^-10 in linear radiance; both sides follow one arithmetic spec, so we hold them to 0).
+RGBA8 (powf tone-map) is allowed +-1 LSB.
+"""
+import numpy as np
+import pytest
+
+import synth_np
+from common import STAT_KEYS, assert_bit_equal, render_hip, render_oracle
+from moonrtx_amd.scene import named_scene
+from moonrtx_amd import renderer
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+L_INF_BAR = 2.0 ** -10
+
+
+@pytest.fixture(scope="module")
+def dem_small():
+    return synth_np.dem(360, 720, seed=5, craters=60)
+
+
+def check(scene, dem, color=None, bg=None, blocks=(1,)):
+    lin_h, hits_h, st_h, _ = render_hip(scene, dem, color, bg, blocks)
+    lin_o, hits_o, st_o = render_oracle(scene, dem, color, bg, blocks)
+    assert np.abs(lin_h - lin_o).max() < L_INF_BAR
+    assert_bit_equal(lin_h, lin_o, "linear radiance")
+    assert_bit_equal(hits_h, hits_o, "hit buffer")
+    assert {k: st_h[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
+    assert lin_o[..., :3].max() > 0.01, "scene rendered black: test is vacuous"
+    return lin_h, st_h
+
+
+def test_math_primitives_bit_exact(native_lib):
+    rng = np.random.default_rng(3)
+    y = np.concatenate([rng.standard_normal(20000), [0, 0, 1, -1, 0.0, 1e-30, -1e-30, 3.0]]).astype(np.float32)
+    x = np.concatenate([rng.standard_normal(20000), [0, 1, 0, 0, -1.0, 1e-30, 1e-30, -3.0]]).astype(np.float32)
+    dev = renderer.probe_atan2(y, x)
+    ref = orc.atan2f(y, x)
+    assert_bit_equal(dev, ref, "atan2 polynomial")
+    assert np.abs(ref.astype(np.float64) - np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() < 4e-7
+
+
+@pytest.mark.parametrize("name", ["S1", "S2", "S3"])
+def test_first_light_1spp(native_lib, dem_small, name):
+    """BASELINE config 1 shape: 1 spp, grey albedo (reduced image so the oracle takes seconds)."""
+    check(named_scene(name, 192, 160, spp_per_launch=1), dem_small)
+
+
+@pytest.mark.parametrize("spp", [2, 4, 8, 16, 32, 64])
+def test_wave_packing_all_spp(native_lib, dem_small, spp):
+    check(named_scene("S1", 72, 56, spp_per_launch=spp), dem_small)
+
+
+def test_accumulation_blocks_match_oracle_and_single_launch(native_lib, dem_small):
+    s = named_scene("S1", 64, 48, spp_per_launch=16)
+    lin_a, _ = check(s, dem_small, blocks=(1, 1, 2))
+    lin_b, _ = check(s, dem_small, blocks=(4,))
+    assert_bit_equal(lin_a, lin_b, "1+1+2 blocks vs 4 blocks in one launch")
+
+
+def test_colour_texture_background_sun_disk(native_lib, dem_small):
+    col = synth_np.colour_map(180, 360)
+    rng = np.random.default_rng(9)
+    bg = rng.integers(0, 255, (64, 128, 4), dtype=np.uint8)
+    s = named_scene("S2", 160, 96, spp_per_launch=4)
+    s.sun_pos, s.sun_radius = (40.0, 3100.0 - 300.0, 25.0), 30.0   # in view, beside the disk
+    _, st = check(s, dem_small, col, bg)
+    assert st["colour_fetches"] > 0 and st["background_fetches"] > 0
+
+
+def test_odd_sizes_and_zoomed_camera(native_lib, dem_small):
+    s = named_scene("S1", 77, 45, spp_per_launch=8)
+    s.vfov_deg = 0.9
+    s.target = (3.0, 0.0, 4.0)
+    check(s, dem_small)
+
+
+def test_ragged_dem_shapes(native_lib):
+    """Non power-of-two, non 2:1 DEMs, and the smallest legal one."""
+    check(named_scene("S2", 48, 48, spp_per_launch=4), synth_np.dem(181, 359, seed=2, craters=10))
+    tiny = np.array([[1.0, 0.99], [0.98, 1.0]], np.float32)
+    check(named_scene("S2", 32, 32, spp_per_launch=4), tiny)
+
+
+def test_sharded_ranks_reassemble_bit_exact(native_lib, dem_small):
+    """world=2 and world=3 on one GPU: each rank renders its tiles, rank 0 unpacks the peers' shards."""
+    from moonrtx_amd.renderer import MoonRT, DeviceBuffer
+    s = named_scene("S1", 100, 70, spp_per_launch=4)
+    lin_1, hits_1, _, _ = render_hip(s, dem_small)
+    for world in (2, 3):
+        rts = []
+        for r in range(world):
+            rt = MoonRT(s.width, s.height, rank=r, world=world, tile=(16, 16))
+            rt.upload_dem(dem_small); rt.apply_scene(s); rt.render(1)
+            rts.append(rt)
+        bufs = []
+        for rt in rts[1:]:
+            b = DeviceBuffer(rt.shard_bytes())
+            rt.pack_shard(b.ptr)
+            bufs.append(b)
+        for r, b in enumerate(bufs, start=1):
+            rts[0].unpack_shard(r, b.ptr)
+        assert_bit_equal(rts[0].read_linear(), lin_1, f"world={world} reassembled radiance")
+        assert_bit_equal(rts[0].read_hits(), hits_1, f"world={world} reassembled hits")
+        for rt in rts:
+            rt.close()
+
+
+def test_rgba8_tonemap_within_one_lsb(native_lib, dem_small):
+    s = named_scene("S2", 64, 64, spp_per_launch=4)
+    lin, _, _, rgba = render_hip(s, dem_small)
+    exp = np.floor(np.clip((0.9 * np.maximum(lin[..., :3], 0)) ** (1 / 2.2), 0, 1) * 255 + 0.5)
+    assert np.abs(rgba[..., :3].astype(np.int32) - exp.astype(np.int32)).max() <= 1
+    assert (rgba[..., 3] == 255).all()
+
+
+def test_device_ldem_pipeline_matches_oracle(native_lib):
+    """a1 on the device (data_loader.py:166-247): block mean, scale, +1, /max -- bit exact."""
+    from moonrtx_amd.renderer import DeviceBuffer, dem_from_ldem
+    for d in (1, 2, 3, 4, 8):
+        src = synth_np.ldem_source(24 * d, 48 * d, seed=d)
+        buf = DeviceBuffer(src.nbytes); buf.upload(src)
+        dst, scale = dem_from_ldem(buf, 24, 48, d)
+        got = dst.download(np.float32, (24, 48))
+        want, wscale = orc.dem_from_ldem(src, d)
+        assert_bit_equal(got, want, f"device LDEM pipeline d={d}")
+        assert np.float32(scale) == np.float32(wscale)
+        assert got.max() == 1.0
+
+
+def test_synthetic_device_dem_is_lola_like_and_renders(native_lib):
+    from moonrtx_amd.renderer import synth_ldem, dem_from_ldem
+    h, w = 360, 720
+    src = synth_ldem(h, w)
+    dst, scale = dem_from_ldem(src, h, w, 1)
+    dem = dst.download(np.float32, (h, w))
+    raw = src.download(np.int16, (h, w))
+    assert raw.min() >= -18200 and raw.max() <= 21600 and raw.std() > 500
+    assert dem.max() == 1.0 and dem.min() > 0.985
+    check(named_scene("S1", 64, 64, spp_per_launch=4), dem)
+
+
+def test_errors_are_reported_not_fatal(native_lib):
+    from moonrtx_amd.renderer import MoonRT, MoonRTError
+    rt = MoonRT(32, 32)
+    with pytest.raises(MoonRTError, match="displacement"):
+        rt.render(1)
+    with pytest.raises(MoonRTError, match="spp_per_launch"):
+        rt.set_params(spp_per_launch=3)
+    with pytest.raises(MoonRTError):
+        rt.set_camera((0, 0, 0), (0, 1, 0), (0, 2, 0), 4.0)
+    rt.close()
+    with pytest.raises(MoonRTError):
+        MoonRT(0, 10)
