@@ -541,7 +541,15 @@ __device__ float vnoise3(float x, float y, float z, uint32_t seed) {
     return 2.0f * (y0 + tz * (y1 - y0)) - 1.0f;
 }
 __device__ float synth_height_km(float px, float py, float pz, int octaves, int levels, uint32_t seed) {
-    float hkm = 0.0f, amp = 2.2f, fr = 2.0f;
+    // LOLA-like hypsometry: hemispheric dichotomy (far-side highlands / near-side lowlands), rare high
+    // massifs reaching ~ +10 km, fractal relief with std ~ 2 km, craters; mean near 0 km.
+    float hkm = 0.9f + 1.9f * vnoise3(px * 1.1f + 5.3f, py * 1.1f + 1.7f, pz * 1.1f - 8.1f, seed ^ 0xA511E9B3u);
+    {
+        const float m = vnoise3(px * 3.3f - 2.2f, py * 3.3f + 6.1f, pz * 3.3f + 0.4f, seed ^ 0x63D83595u);
+        const float mp = fmaxf(m, 0.0f);
+        hkm += 14.0f * mp * mp * mp;
+    }
+    float amp = 2.0f, fr = 2.0f;
     for (int o = 0; o < octaves; o++) {
         hkm += amp * vnoise3(px * fr + 17.3f, py * fr - 4.1f, pz * fr + 9.7f, seed + 101u * (uint32_t)o);
         fr *= 2.0f; amp *= 0.56f;

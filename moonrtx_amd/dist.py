@@ -1,0 +1,74 @@
+"""Image-tile sharding across the GPUs of one node + the one exchange step of the path.
+
+New in this build (the reference is single-GPU): every pixel sample is independent
+given the read-only scene, so the frame is cut into tile_w x tile_h tiles dealt round-robin to ranks
+(tile t -> rank t % world: sky, limb, terminator and night side are spread evenly), each rank renders
+its tiles for all samples, and ONE gather brings the packed float4 radiance + hit tiles to rank 0 over
+xGMI (RCCL `gather` = grouped send/recv: every peer uses its own direct link to the root).  No
+reduction is needed -- tiles are disjoint -- and the RNG is keyed by (pixel, sample), so 1-, 2-, 4- and
+8-GPU frames are bit-identical.
+
+One process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" for the CPU tests).
+torch is plumbing here: process group, device buffers for the collective, streams.
+"""
+import os
+
+
+def tiles_of(rank, world, width, height, tile=(32, 32)):
+    """Raster indices of the tiles a rank owns, and the padded slot count every rank packs."""
+    tx = (width + tile[0] - 1) // tile[0]
+    ty = (height + tile[1] - 1) // tile[1]
+    n = tx * ty
+    return list(range(rank, n, world)), (n + world - 1) // world
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(backend=None):
+    """Join the group torchrun described in the environment (MASTER_ADDR must be 127.0.0.1 on one node)."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_rank_world()
+    if world == 1:
+        return rank, world, local
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FrameGather:
+    """Reusable buffers + the gather of packed shards to rank 0.
+
+    `renderer` needs shard_bytes(), pack_shard(ptr), unpack_shard(src_rank, ptr), rank, world -- the
+    MoonRT surface (mrtx_shard_bytes / mrtx_pack_shard / mrtx_unpack_shard in include/moonrt.h)."""
+
+    def __init__(self, renderer, device):
+        import torch
+        self.torch = torch
+        self.r = renderer
+        self.rank, self.world = renderer.rank, renderer.world
+        self.nbytes = renderer.shard_bytes()
+        self.send = torch.empty(self.nbytes // 4, dtype=torch.float32, device=device)
+        self.recv = None
+        if self.rank == 0 and self.world > 1:
+            self.recv = [torch.empty_like(self.send) for _ in range(self.world)]
+
+    def gather(self):
+        """After every rank has rendered: bring all tiles to rank 0's framebuffer."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        torch = self.torch
+        self.r.pack_shard(self.send.data_ptr())          # synchronous on the renderer's stream
+        dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
+        if self.send.is_cuda:
+            torch.cuda.synchronize()
+        if self.rank == 0:
+            for src in range(1, self.world):
+                self.r.unpack_shard(src, self.recv[src].data_ptr())

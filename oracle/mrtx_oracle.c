@@ -33,6 +33,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef struct OrcScene {
     int32_t width, height;
@@ -591,3 +594,14 @@ float orc_dem_from_ldem(const int16_t* src, int32_t h, int32_t w, int32_t d, flo
 }
 
 int orc_sizeof_scene(void) { return (int)sizeof(OrcScene); }
+
+/* number of OpenMP threads orc_render uses from now on; returns the count in effect */
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}

@@ -76,9 +76,16 @@ def lib():
         L.orc_dem_from_ldem.restype = C.c_float
         L.orc_dem_from_ldem.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.orc_sizeof_scene.restype = C.c_int
+        L.orc_set_threads.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
         assert L.orc_sizeof_scene() == C.sizeof(OrcScene), "OrcScene layout mismatch"
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """Cap the OpenMP team of orc_render; returns the thread count in effect."""
+    return int(lib().orc_set_threads(int(n)))
 
 
 def atan2f(y, x):
