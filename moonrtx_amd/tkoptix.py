@@ -1,0 +1,466 @@
+"""TkOptiX-compatible facade over MoonRT: the object MoonRTX keeps in `self.rt`.
+
+Every member the reference touches on its renderer object (call sites cited per
+method) is provided with the same name, argument meaning and threading contract:
+
+  * scene edits may come from any thread; multi-call edits are grouped under `rt._padlock`, a re-entrant
+    lock (moon_renderer.py:849-852);
+  * a render thread runs accumulation cycles: after every launch it calls `on_launch_finished(rt)`
+    (moon_renderer.py:574, renderer_status.py:239), after the last launch of a cycle it calls the
+    `set_accum_done_cb` callback WITH the padlock held (renderer_video.py:260, :276-281), then idles
+    until `refresh_scene()` (moon_renderer.py:867-871);
+  * `_get_hit_at(x, y)` reads the host copy of the hit buffer, no GPU call (moon_renderer.py:1138).
+
+What differs, by design: there is no Tk window here (no Tk on a headless GPU node) -- `_root`/`_canvas`
+are None and the `_gui_*` handler slots are plain attributes a viewer may call.  One launch adds
+`spp_per_launch` samples per pixel (a whole 64-lane wavefront per pixel) instead of one:
+max_accumulation_frames=64 is ONE launch, max_accumulation_frames=1 (the interactive preview,
+moon_renderer.py:457-488) is a 1-spp launch.  Overlay graph geometry (set_graph) and the NVENC encoder
+are accepted / refused explicitly: they are outside this round's scope.
+"""
+import threading
+import warnings
+
+import numpy as np
+
+__version__ = "0.19.2"   # the PlotOptiX API level this facade mirrors (main.py:185-201)
+
+
+def _as3(v):
+    a = np.asarray(v, float).reshape(-1)
+    if a.size == 1:
+        return np.array([a[0]] * 3)
+    return a[:3].copy()
+
+
+class _OptixShim:
+    """`rt._optix.get_camera_fov(0)` / `.set_camera_fov(f)` (renderer_navigation.py:508, :521, renderer_fov.py:61)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def get_camera_fov(self, handle=0):
+        return float(self._o._cam["fov"])
+
+    def set_camera_fov(self, fov):
+        self._o.update_camera(fov=float(fov))
+
+
+class TkOptiX:
+    def __init__(self, width=-1, height=-1, on_launch_finished=None, on_rt_completed=None, start_now=False,
+                 device=0, backend=None, **_ignored):
+        if width <= 0 or height <= 0:
+            raise ValueError("headless backend needs explicit width and height")
+        self._width, self._height = int(width), int(height)
+        if backend is None:
+            from .renderer import MoonRT
+            backend = MoonRT(self._width, self._height, device=device)
+        self._rt = backend
+        self._padlock = threading.RLock()
+        self._on_launch_finished = on_launch_finished
+        self._on_rt_completed = on_rt_completed
+        self._accum_done_cb = None
+        self._optix = _OptixShim(self)
+        # viewer plumbing the reference pokes at (moon_renderer.py:998-1201); no Tk here
+        self._root = None
+        self._canvas = None
+        self._status_action = self._status_action_text = self._status_fps = None
+        self._view_orientation = None
+        self._any_mouse = self._any_key = self._right_mouse = False
+        self._selection_handle = None
+        self._mouse_from_x = self._mouse_from_y = self._mouse_to_x = self._mouse_to_y = 0
+        for slot in ("_gui_key_pressed", "_gui_motion", "_gui_pressed_left", "_gui_released_left",
+                     "_gui_motion_pressed", "_gui_apply_scene_edits"):
+            setattr(self, slot, lambda *a, **k: None)
+        # state
+        self._is_started = False
+        self._is_closed = False
+        self._thread = None
+        self._wake = threading.Condition(self._padlock)
+        self._dirty = True
+        self._params = {"min_accumulation_step": 1, "max_accumulation_frames": 64}
+        self._floats = {}
+        self._uints = {}
+        self._postproc = []
+        self._textures = {}
+        self._materials = {}
+        self._geoms = {}
+        self._graphs = {}
+        self._cam_name = None
+        self._cam = {"eye": np.array([0.0, -300.0, 0.0]), "target": np.zeros(3), "up": np.array([0.0, 0.0, 1.0]),
+                     "fov": 4.2421875, "type": "Pinhole"}
+        self._lights = {}
+        self._moon_name = None
+        self._sun_name = None
+        self._frames_done = 0
+        self._image = np.zeros((self._height, self._width, 4), np.uint8)
+        self._hits = np.zeros((self._height, self._width, 4), np.float32)
+        self._warned = set()
+        if start_now:
+            self.start()
+
+    # ------------------------------------------------------------------ parameters
+    def set_param(self, **kwargs):
+        """set_param(min_accumulation_step=, max_accumulation_frames=) -- moon_renderer.py:578, :475, :487."""
+        with self._padlock:
+            for k, v in kwargs.items():
+                if k not in ("min_accumulation_step", "max_accumulation_frames", "light_shading", "compute_timeout",
+                             "rt_timeout", "save_albedo", "save_normals"):
+                    raise ValueError(f"unknown parameter {k}")
+                self._params[k] = int(v)
+            self._dirty = True
+            self._wake.notify_all()
+
+    def get_param(self, name):
+        return self._params.get(name)
+
+    def set_float(self, name, x, y=None, z=None, refresh=False):
+        """set_float("scene_epsilon"|"marching_step"|"marching_step_eps"|"tonemap_exposure"|"tonemap_gamma", x)
+        -- moon_renderer.py:586-599, :367."""
+        with self._padlock:
+            self._floats[name] = float(x)
+            if name not in ("tonemap_exposure", "tonemap_gamma"):
+                self._dirty = True                      # geometry-affecting: restart the cycle
+            self._wake.notify_all()
+
+    def set_uint(self, name, x, y=None, refresh=False):
+        """set_uint("path_seg_range", 2, 4) -- moon_renderer.py:583."""
+        with self._padlock:
+            self._uints[name] = (int(x),) if y is None else (int(x), int(y))
+            self._dirty = True
+
+    def set_ambient(self, color, refresh=False):
+        """set_ambient(0) -- moon_renderer.py:595.  Only zero ambient exists in this scene."""
+        if float(np.max(np.asarray(color, float))) != 0.0:
+            self._warn_once("ambient", "non-zero ambient light is not supported by this backend (MoonRTX uses 0)")
+
+    def add_postproc(self, stage, refresh=False):
+        """add_postproc("Gamma") -- moon_renderer.py:600; "Overlay" -- renderer_video.py:143."""
+        self._postproc.append(stage)
+        if stage not in ("Gamma", "Overlay"):
+            self._warn_once("pp" + stage, f"post-processing stage {stage!r} is not implemented")
+
+    # ------------------------------------------------------------------ resources
+    def set_background_mode(self, mode, refresh=False):
+        self._bg_mode = mode
+
+    def set_background(self, bg, gamma=1.0, rt_format="Float4", refresh=False, **_k):
+        """set_background(star_map, gamma=, rt_format="UByte4") / set_background(0) -- moon_renderer.py:606-609.
+
+        A float (h, w, 3) map in display space is brought to the renderer's linear space with ^gamma (so the
+        Gamma stage shows it unchanged) and stored as RGBA8."""
+        with self._padlock:
+            if np.isscalar(bg) or np.asarray(bg).ndim < 2:
+                self._rt.upload_background(None)
+            else:
+                a = np.asarray(bg)
+                if a.dtype != np.uint8:
+                    lin = np.power(np.clip(a[..., :3].astype(np.float32), 0.0, 1.0), np.float32(gamma))
+                    rgb = np.floor(lin * 255.0 + 0.5).astype(np.uint8)
+                else:
+                    rgb = a[..., :3]
+                rgba = np.empty(rgb.shape[:2] + (4,), np.uint8)
+                rgba[..., :3] = rgb
+                rgba[..., 3] = 255
+                self._rt.upload_background(rgba)
+            self._dirty = True
+
+    def set_texture_2d(self, name, data, addr_mode=None, filter_mode=None, keep_on_host=False, refresh=False, **_k):
+        """set_texture_2d("moon_color", rgba_u8) -- moon_renderer.py:614; overlay textures renderer_video.py:137."""
+        a = np.asarray(data)
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 4:
+            raise ValueError("textures are (h, w, 4) uint8 arrays (data_loader.py:345-368)")
+        with self._padlock:
+            self._textures[name] = a
+            self._bind_moon_material()
+
+    def setup_material(self, name, data):
+        """setup_material("flat", {...}) -- moon_renderer.py:647, renderer_labels.py:288."""
+        with self._padlock:
+            self._materials[name] = dict(data)
+            self._bind_moon_material()
+
+    def update_material(self, name, data, refresh=False):
+        """update_material("diffuse", {"ColorTextures": ["moon_color"], ...}) -- moon_renderer.py:617."""
+        self.setup_material(name, data)
+
+    def _bind_moon_material(self):
+        moon = self._geoms.get(self._moon_name) if self._moon_name else None
+        mat = self._materials.get(moon["mat"] if moon else "diffuse", {})
+        tex = [t for t in mat.get("ColorTextures", []) if t in self._textures]
+        if tex:
+            self._rt.upload_color(self._textures[tex[0]])
+            self._dirty = True
+
+    def set_displacement(self, name, data, addr_mode=None, keep_on_host=False, refresh=False, **_k):
+        """set_displacement("moon", elevation_f32, refresh=False) -- moon_renderer.py:624."""
+        a = np.asarray(data)
+        if a.ndim != 2:
+            raise ValueError("displacement map must be a 2-D array")
+        with self._padlock:
+            self._rt.upload_dem(a.astype(np.float32, copy=False))
+            self._dirty = True
+
+    # ------------------------------------------------------------------ geometry
+    def set_data(self, name, pos=None, c=None, r=None, u=None, v=None, w=None, geom="ParticleSet", geom_attr=None,
+                 mat="diffuse", rnd=True, **_k):
+        """set_data("moon", geom="ParticleSetTextured", geom_attr="DisplacedSurface", pos, u, v, r) and
+        set_data("sun_disk", geom="ParticleSet", mat="flat", pos, r, c) -- moon_renderer.py:620-621, :648-650."""
+        with self._padlock:
+            g = {"geom": geom, "attr": geom_attr, "mat": mat, "pos": _as3(np.asarray(pos, float).reshape(-1)[:3]),
+                 "r": float(np.asarray(r, float).reshape(-1)[0]) if r is not None else 1.0,
+                 "u": _as3(u) if u is not None else np.array([0.0, 0.0, 1.0]),
+                 "v": _as3(v) if v is not None else np.array([0.0, -1.0, 0.0]),
+                 "c": float(np.mean(np.asarray(c, float))) if c is not None else 0.94}
+            self._geoms[name] = g
+            if geom_attr == "DisplacedSurface" or geom == "ParticleSetTextured":
+                self._moon_name = name
+                self._bind_moon_material()
+            elif self._sun_name is None or name == self._sun_name:
+                self._sun_name = name
+            self._push_geometry()
+
+    def update_data(self, name, pos=None, c=None, r=None, u=None, v=None, w=None, **_k):
+        """update_data("moon", u=, v=) / update_data("sun_disk", pos=, r=) -- moon_renderer.py:854-855."""
+        with self._padlock:
+            g = self._geoms[name]
+            if pos is not None:
+                g["pos"] = _as3(np.asarray(pos, float).reshape(-1)[:3])
+            if r is not None:
+                g["r"] = float(np.asarray(r, float).reshape(-1)[0])
+            if u is not None:
+                g["u"] = _as3(u)
+            if v is not None:
+                g["v"] = _as3(v)
+            if c is not None:
+                g["c"] = float(np.mean(np.asarray(c, float)))
+            self._push_geometry()
+
+    def _push_geometry(self):
+        if self._moon_name:
+            m = self._geoms[self._moon_name]
+            self._rt.set_moon_frame(m["pos"], m["r"], m["u"], m["v"])
+        if self._sun_name and self._sun_name in self._geoms:
+            s = self._geoms[self._sun_name]
+            self._rt.set_sun_disk(s["pos"], s["r"], s["c"])
+        self._dirty = True
+        self._wake.notify_all()
+
+    def set_graph(self, name, pos=None, edges=None, r=None, c=None, mat=None, **_k):
+        """Overlay tubes (renderer_labels.py:295-300, renderer_pins.py:54): stored, not yet rendered."""
+        self._graphs[name] = {"pos": np.asarray(pos), "edges": np.asarray(edges), "r": r, "c": c, "mat": mat}
+        self._warn_once("graph", "overlay graph geometry is stored but not rendered by this backend yet")
+
+    def update_graph(self, name, pos=None, r=None, c=None, **_k):
+        if name in self._graphs and pos is not None:
+            self._graphs[name]["pos"] = np.asarray(pos)
+
+    def delete_geometry(self, name):
+        self._graphs.pop(name, None)
+        with self._padlock:
+            if self._geoms.pop(name, None) is not None and name == self._sun_name:
+                self._rt.set_sun_disk((0, 0, 0), 0.0, 0.0)
+                self._sun_name = None
+                self._dirty = True
+
+    # ------------------------------------------------------------------ camera / light
+    def setup_camera(self, name, eye=None, target=None, up=None, cam_type="Pinhole", fov=None, make_current=True, **_k):
+        """setup_camera(name, cam_type=, eye=, target=, up=, fov=, aperture_*=, focal_scale=) -- moon_renderer.py:627-635."""
+        if cam_type != "Pinhole":
+            self._warn_once("cam", f"camera type {cam_type!r} renders as Pinhole (shared_types.py:56-69)")
+        self._cam_name = name
+        self.update_camera(name, eye=eye, target=target, up=up, fov=fov)
+
+    def update_camera(self, name=None, eye=None, target=None, up=None, fov=None, **_k):
+        """update_camera(name, eye=, target=, up=, fov=), any subset -- renderer_navigation.py:73, :150, :224, :450."""
+        with self._padlock:
+            if eye is not None:
+                self._cam["eye"] = _as3(eye)
+            if target is not None:
+                self._cam["target"] = _as3(target)
+            if up is not None:
+                self._cam["up"] = _as3(up)
+            if fov is not None:
+                self._cam["fov"] = float(fov)
+            self._rt.set_camera(self._cam["eye"], self._cam["target"], self._cam["up"], self._cam["fov"])
+            self._dirty = True
+            self._wake.notify_all()
+
+    def get_camera(self, name=None):
+        """-> dict with "Eye", "Target", "Up" (moon_renderer.py:565-567, renderer_navigation.py:60-62)."""
+        with self._padlock:
+            return {"Eye": self._cam["eye"].tolist(), "Target": self._cam["target"].tolist(),
+                    "Up": self._cam["up"].tolist(), "Fov": self._cam["fov"], "Type": self._cam["type"]}
+
+    def setup_light(self, name, light_type=None, pos=None, color=None, radius=None, in_geometry=True, **_k):
+        """setup_light("sun", color=brightness*460.53, radius=100, in_geometry=False) -- moon_renderer.py:640-641."""
+        with self._padlock:
+            self._lights[name] = {"pos": _as3(pos) if pos is not None else np.array([0.0, -21460.0, 0.0]),
+                                  "radiance": float(np.mean(np.asarray(color, float))) if color is not None else 10.0,
+                                  "radius": float(radius) if radius is not None else 1.0}
+            self._push_light(name)
+
+    def update_light(self, name, pos=None, color=None, radius=None, **_k):
+        """update_light("sun", pos=, color=, radius=) -- moon_renderer.py:347, :859-860."""
+        with self._padlock:
+            lt = self._lights[name]
+            if pos is not None:
+                lt["pos"] = _as3(pos)
+            if color is not None:
+                lt["radiance"] = float(np.mean(np.asarray(color, float)))
+            if radius is not None:
+                lt["radius"] = float(radius)
+            self._push_light(name)
+
+    def _push_light(self, name):
+        lt = self._lights[name]
+        self._rt.set_light(lt["pos"], lt["radius"], lt["radiance"])
+        self._dirty = True
+        self._wake.notify_all()
+
+    # ------------------------------------------------------------------ render loop
+    def _cycle_plan(self):
+        n = max(1, int(self._params["max_accumulation_frames"]))
+        s = 1
+        while s * 2 <= min(n, 64):
+            s *= 2
+        return s, max(1, n // s)            # samples per launch, launches per cycle
+
+    def _push_params(self, spp):
+        f = self._floats
+        kw = dict(spp_per_launch=spp, max_spp=int(self._params["max_accumulation_frames"]))
+        for src, dst in (("scene_epsilon", "scene_epsilon"), ("marching_step", "marching_step"),
+                         ("marching_step_eps", "marching_step_eps"), ("tonemap_exposure", "tonemap_exposure"),
+                         ("tonemap_gamma", "tonemap_gamma")):
+            if src in f:
+                kw[dst] = f[src]
+        if "path_seg_range" in self._uints and len(self._uints["path_seg_range"]) == 2:
+            kw["path_seg_min"], kw["path_seg_max"] = self._uints["path_seg_range"]
+        self._rt.set_params(**kw)
+
+    def _launch_once(self):
+        """One launch under the padlock: (re)start the cycle if the scene changed, add one block, read back."""
+        spp, launches = self._cycle_plan()
+        if self._dirty:
+            self._rt.reset()
+            self._push_params(spp)
+            self._frames_done = 0
+            self._dirty = False
+        else:
+            self._push_params(spp)
+        self._rt.render(1)
+        self._frames_done += 1
+        self._image = self._rt.read_rgba8()
+        self._hits = self._rt.read_hits()
+        return self._frames_done >= launches
+
+    def _render_loop(self):
+        while True:
+            with self._padlock:
+                while not self._is_closed and not self._dirty and self._frames_done >= self._cycle_plan()[1]:
+                    self._wake.wait(0.25)
+                if self._is_closed:
+                    return
+                done = self._launch_once()
+            if self._on_launch_finished is not None:
+                self._on_launch_finished(self)                   # render thread, lock released
+            if done:
+                with self._padlock:
+                    if self._on_rt_completed is not None:
+                        self._on_rt_completed(self)
+                    cb = self._accum_done_cb
+                    if cb is not None and not self._dirty:
+                        cb(self)                                 # padlock held (renderer_video.py:276-281)
+
+    def start(self):
+        """rt.start() -- moon_renderer.py:875-878: spawn the render thread (no Tk mainloop here)."""
+        if self._is_started:
+            return
+        self._is_started = True
+        self._thread = threading.Thread(target=self._render_loop, name="moonrt-render", daemon=True)
+        self._thread.start()
+
+    def refresh_scene(self):
+        """rt.refresh_scene() -- moon_renderer.py:488, :871: force a new accumulation cycle."""
+        with self._padlock:
+            self._dirty = True
+            self._wake.notify_all()
+
+    def render_cycle(self):
+        """Headless helper: run one full accumulation cycle synchronously on the calling thread."""
+        with self._padlock:
+            self._dirty = True
+            while not self._launch_once():
+                pass
+            return self._image
+
+    def set_accum_done_cb(self, cb):
+        """set_accum_done_cb(cb_or_None) -- renderer_video.py:260, :322."""
+        with self._padlock:
+            self._accum_done_cb = cb
+
+    def set_launch_finished_cb(self, cb):
+        self._on_launch_finished = cb
+
+    def close(self):
+        """rt.close() -- moon_renderer.py:880-884."""
+        with self._padlock:
+            self._is_closed = True
+            self._wake.notify_all()
+        if self._thread is not None and self._thread is not threading.current_thread():
+            self._thread.join(timeout=10.0)
+        with self._padlock:
+            if self._rt is not None:
+                self._rt.close()
+                self._rt = None
+        self._is_started = False
+
+    # ------------------------------------------------------------------ read-back
+    def _get_image_xy(self, wx, wy):
+        """Window -> image pixel (moon_renderer.py:1137); identity without a scaled Tk canvas."""
+        return int(wx), int(wy)
+
+    def _get_hit_at(self, x, y):
+        """-> (hx, hy, hz, hd), hd <= 0 == miss (moon_renderer.py:1138-1142, renderer_navigation.py:195-203)."""
+        if 0 <= x < self._width and 0 <= y < self._height:
+            h = self._hits[int(y), int(x)]
+            return float(h[0]), float(h[1]), float(h[2]), float(h[3])
+        return 0.0, 0.0, 0.0, -1.0
+
+    def get_image(self):
+        return self._image
+
+    def save_image(self, file_name, bps="Bps8"):
+        """save_image(path, bps="Bps8"|"Bps16") -- renderer_dialogs.py:1222-1224."""
+        from PIL import Image
+        bps = getattr(bps, "name", bps)
+        with self._padlock:
+            if str(bps) == "Bps16":
+                lin = self._rt.read_linear()[..., :3]
+                g = 1.0 / float(self._floats.get("tonemap_gamma", 2.2))
+                e = float(self._floats.get("tonemap_exposure", 0.9))
+                img = np.clip(np.power(np.maximum(e * lin, 0.0), g), 0.0, 1.0)
+                arr = np.floor(img * 65535.0 + 0.5).astype(np.uint16)
+                try:
+                    import imageio.v3 as iio
+                    iio.imwrite(file_name, arr)
+                    return
+                except Exception:
+                    arr8 = (arr >> 8).astype(np.uint8)
+                    Image.fromarray(arr8).save(file_name)
+                    return
+            Image.fromarray(self._image[..., :3]).save(file_name)
+
+    # ------------------------------------------------------------------ encoder (NVENC in the reference)
+    def encoder_create(self, *a, **k):
+        raise NotImplementedError("video encoding is outside this backend (renderer_video.py:219-260 uses NVENC)")
+
+    encoder_start = encoder_stop = encoder_create
+
+    def encoder_is_open(self):
+        return False
+
+    def _warn_once(self, key, msg):
+        if key not in self._warned:
+            self._warned.add(key)
+            warnings.warn(msg, stacklevel=3)

@@ -1,0 +1,180 @@
+"""The PlotOptiX-named facade driven the way moon_renderer.py drives `self.rt`, on a recording backend
+(no GPU): parameter mapping, scene plumbing, render-thread callback contract."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from moonrtx_amd.tkoptix import TkOptiX
+from moonrtx_amd.materials import m_diffuse, m_flat
+from moonrtx_amd import scene as sc
+
+
+class RecordingBackend:
+    def __init__(self, w, h):
+        self.width, self.height, self.rank, self.world = w, h, 0, 1
+        self.calls = []
+        self.blocks = 0
+        self.closed = False
+
+    def __getattr__(self, name):
+        def rec(*a, **k):
+            self.calls.append((name, a, k))
+            if name == "render":
+                self.blocks += a[0] if a else 1
+                return {"kernel_ms": 0.0}
+            if name == "reset":
+                self.blocks = 0
+            if name == "read_rgba8":
+                return np.full((self.height, self.width, 4), min(255, self.blocks), np.uint8)
+            if name == "read_hits":
+                h = np.zeros((self.height, self.width, 4), np.float32); h[2, 3] = (1, 2, 3, 290.5); return h
+            if name == "read_linear":
+                return np.zeros((self.height, self.width, 4), np.float32)
+            if name == "close":
+                self.closed = True
+        return rec
+
+    def last(self, name):
+        return [c for c in self.calls if c[0] == name][-1]
+
+
+def drive_like_init_renderer(rt, elevation, color, gamma=2.2, brightness=80):
+    """The call sequence of MoonRenderer.init_renderer (moon_renderer.py:570-650)."""
+    rt.set_param(min_accumulation_step=1, max_accumulation_frames=64)
+    rt.set_uint("path_seg_range", 2, 4)
+    rt.set_float("scene_epsilon", 1.0e-4)
+    rt.set_float("marching_step", 5.0e-3)
+    rt.set_float("marching_step_eps", 3.0e-4)
+    rt.set_ambient(0)
+    rt.set_float("tonemap_exposure", 0.9)
+    rt.set_float("tonemap_gamma", gamma)
+    rt.add_postproc("Gamma")
+    rt.set_background(0)
+    rt.set_texture_2d("moon_color", color)
+    mat = m_diffuse.copy()
+    mat["ColorTextures"] = ["moon_color"]
+    rt.update_material("diffuse", mat)
+    rt.set_data("moon", geom="ParticleSetTextured", geom_attr="DisplacedSurface", pos=[0, 0, 0], u=[0, 0, 1],
+                v=[0, -1, 0], r=10.0)
+    rt.set_displacement("moon", elevation, refresh=False)
+    rt.setup_camera("cam1", cam_type="Pinhole", eye=[0, -300, 0], target=[0, 0, 0], up=[0, 0, 1], fov=4.2422,
+                    aperture_radius=0.01, aperture_fract=0.2, focal_scale=0.7)
+    rt.setup_light("sun", color=brightness * sc.SUN_BRIGHTNESS_SCALE, radius=100, in_geometry=False)
+    flat = dict(m_flat); flat["OcclusionProgram"] = "x"; flat["VarFloat4"] = {"x": [1, 1, 1, 0]}
+    rt.setup_material("flat", flat)
+    rt.set_data("sun_disk", geom="ParticleSet", mat="flat", pos=[[0.0, 3100.0, 0.0]], r=0.01, c=2.0)
+
+
+def make():
+    be = RecordingBackend(16, 8)
+    events = []
+    rt = TkOptiX(width=16, height=8, on_launch_finished=lambda r: events.append(("launch", threading.current_thread().name)),
+                 backend=be)
+    return rt, be, events
+
+
+def test_init_sequence_maps_onto_the_c_abi_surface():
+    rt, be, _ = make()
+    elev = np.ones((4, 8), np.float32)
+    col = np.zeros((4, 8, 4), np.uint8)
+    drive_like_init_renderer(rt, elev, col)
+    assert be.last("upload_dem")[1][0].shape == (4, 8)
+    assert be.last("upload_color")[1][0].shape == (4, 8, 4)
+    assert be.last("upload_background")[1] == (None,)
+    name, a, _ = be.last("set_moon_frame")
+    assert np.allclose(a[0], 0) and a[1] == 10.0 and np.allclose(a[2], (0, 0, 1)) and np.allclose(a[3], (0, -1, 0))
+    name, a, _ = be.last("set_camera")
+    assert np.allclose(a[0], (0, -300, 0)) and abs(a[3] - 4.2422) < 1e-12
+    name, a, _ = be.last("set_light")
+    assert a[1] == 100 and abs(a[2] - 80 * 460.5316) < 1e-6
+    name, a, _ = be.last("set_sun_disk")
+    assert np.allclose(a[0], (0, 3100, 0)) and a[1] == 0.01 and a[2] == 2.0
+    cam = rt.get_camera("cam1")
+    assert cam["Eye"] == [0, -300, 0] and cam["Target"] == [0, 0, 0] and cam["Up"] == [0, 0, 1]
+    assert rt._optix.get_camera_fov(0) == pytest.approx(4.2422)
+    rt.close()
+    assert be.closed
+
+
+def test_update_view_sequence_and_cycle_restart():
+    """moon_renderer.py:852-871: camera move + update_data + update_light under the padlock, then refresh."""
+    rt, be, _ = make()
+    drive_like_init_renderer(rt, np.ones((4, 8), np.float32), np.zeros((4, 8, 4), np.uint8))
+    img = rt.render_cycle()
+    assert img[0, 0, 0] == 1                     # 64 frames == ONE 64-spp launch
+    assert be.last("set_params")[2]["spp_per_launch"] == 64
+    R = sc.libration_rotation(3.0, -5.0)
+    with rt._padlock:
+        with rt._padlock:                        # re-entrant
+            cam = rt.get_camera("cam1")
+            rt.update_camera("cam1", eye=(np.array(cam["Eye"]) * 1.01).tolist())
+        rt.update_data("moon", u=R[:, 2], v=-R[:, 1])
+        rt.update_data("sun_disk", pos=[[10.0, 2800.0, 5.0]], r=33.0)
+        rt.update_light("sun", pos=sc.light_position(77, -70), radius=99.8)
+    assert np.allclose(be.last("set_moon_frame")[1][2], R[:, 2])
+    assert be.last("set_sun_disk")[1][1] == 33.0
+    assert np.allclose(be.last("set_light")[1][0], sc.light_position(77, -70)) and be.last("set_light")[1][1] == 99.8
+    n_reset = sum(1 for c in be.calls if c[0] == "reset")
+    rt.render_cycle()
+    assert sum(1 for c in be.calls if c[0] == "reset") == n_reset + 1
+    # preview switch (moon_renderer.py:475): one frame per cycle -> a 1-spp launch
+    rt.set_param(max_accumulation_frames=1)
+    rt.render_cycle()
+    assert be.last("set_params")[2]["spp_per_launch"] == 1
+    rt._optix.set_camera_fov(2.0)
+    assert be.last("set_camera")[1][3] == 2.0
+    assert rt._get_hit_at(3, 2) == (1.0, 2.0, 3.0, 290.5) and rt._get_hit_at(99, 99)[3] <= 0
+    rt.close()
+
+
+def test_render_thread_callbacks_and_padlock_contract():
+    """on_launch_finished after every launch from the render thread; accum-done callback runs with the
+    padlock held and may edit the scene re-entrantly (renderer_video.py:276-318)."""
+    rt, be, events = make()
+    drive_like_init_renderer(rt, np.ones((4, 8), np.float32), np.zeros((4, 8, 4), np.uint8))
+    rt.set_param(max_accumulation_frames=128)    # 2 launches of 64 per cycle
+    done = threading.Event()
+    seen = {"cycles": 0, "owned": None}
+
+    def accum_done(r):
+        seen["cycles"] += 1
+        seen["owned"] = r._padlock._is_owned()
+        if seen["cycles"] < 3:
+            r.update_light("sun", radius=100.0 + seen["cycles"])   # re-entrant edit, as update_view does
+            r.refresh_scene()
+        else:
+            r.set_accum_done_cb(None)
+            done.set()
+
+    rt.set_accum_done_cb(accum_done)
+    rt.start()
+    assert rt._is_started
+    assert done.wait(10.0), "render thread never completed three cycles"
+    time.sleep(0.1)
+    assert seen["owned"] is True
+    launches = [e for e in events if e[0] == "launch"]
+    assert len(launches) >= 6 and all(t == "moonrt-render" for _, t in launches)
+    n = len(events)
+    time.sleep(0.4)
+    assert len(events) == n, "the loop must idle after a converged cycle until refresh_scene()"
+    rt.refresh_scene()
+    time.sleep(0.6)
+    assert len(events) >= n + 2
+    rt.close()
+    assert not rt._is_started
+
+
+def test_unsupported_pieces_are_explicit():
+    rt, be, _ = make()
+    with pytest.warns(UserWarning):
+        rt.set_graph("grid", pos=np.zeros((2, 3)), edges=np.zeros((1, 2), np.int32), r=0.01, c=1.0)
+    with pytest.raises(NotImplementedError):
+        rt.encoder_create(fps=30, bitrate=8)
+    assert rt.encoder_is_open() is False
+    with pytest.raises(ValueError):
+        rt.set_param(bogus=1)
+    with pytest.raises(ValueError):
+        rt.set_texture_2d("t", np.zeros((4, 4, 3), np.uint8))
+    rt.close()

@@ -1,0 +1,56 @@
+"""The PlotOptiX-named facade on the real HIP backend: driven with moon_renderer.py's call sequence it must
+produce the oracle's frame for the same scene."""
+import numpy as np
+import pytest
+
+import synth_np
+from common import assert_bit_equal, render_oracle
+from test_facade_cpu import drive_like_init_renderer
+from moonrtx_amd import scene as sc
+from moonrtx_amd.tkoptix import TkOptiX
+
+pytestmark = pytest.mark.gpu
+
+
+def test_facade_frame_equals_oracle(native_lib):
+    W, H = 96, 64
+    dem = synth_np.dem(180, 360, seed=5, craters=30)
+    col = synth_np.colour_map(90, 180)
+    launches = []
+    rt = TkOptiX(width=W, height=H, on_launch_finished=lambda r: launches.append(1))
+    drive_like_init_renderer(rt, dem, col, gamma=2.2, brightness=80)
+    rt.set_param(max_accumulation_frames=16)
+    # update_view (moon_renderer.py:840-860) for scene S1
+    s = sc.named_scene("S1", W, H, spp_per_launch=16)
+    with rt._padlock:
+        rt.update_camera("cam1", eye=list(s.eye))
+        rt.update_data("moon", u=s.u, v=s.v)
+        rt.update_data("sun_disk", pos=[list(s.sun_pos)], r=s.sun_radius)
+        rt.update_light("sun", pos=list(s.light_pos), radius=s.light_radius)
+    img = rt.render_cycle()
+    lin = rt._rt.read_linear()
+    hits = rt._rt.read_hits()
+    s.vfov_deg = 4.2422
+    lin_o, hits_o, _ = render_oracle(s, dem, col)
+    assert_bit_equal(lin, lin_o, "facade frame vs oracle")
+    assert_bit_equal(hits, hits_o, "facade hits vs oracle")
+    assert img.shape == (H, W, 4) and img[..., :3].max() > 50
+    # picking path: renderer_navigation.py:452-492 on the facade's hit buffer
+    hx, hy, hz, hd = rt._get_hit_at(W // 2 + 10, H // 2)
+    assert hd > 280 and 9.8 < np.linalg.norm([hx, hy, hz]) <= 10.0
+    lat, lon = sc.selenographic((hx, hy, hz), s.rotation)
+    assert -90 <= lat <= 90 and -180 <= lon <= 180
+    rt.close()
+
+
+def test_facade_render_thread_on_gpu(native_lib):
+    import threading
+    dem = synth_np.dem(90, 180, seed=1, craters=5)
+    done = threading.Event()
+    rt = TkOptiX(width=48, height=32)
+    drive_like_init_renderer(rt, dem, synth_np.colour_map(45, 90))
+    rt.set_accum_done_cb(lambda r: done.set())
+    rt.start()
+    assert done.wait(30.0)
+    assert rt.get_image()[..., :3].max() > 0
+    rt.close()
