@@ -89,8 +89,9 @@ int mrtx_abi_version(void);
  * `host` is the float32 (h, w) array load_elevation_data returns (data_loader.py:166-247):
  * equirectangular, row 0 = +90 deg, column 0 = -180 deg, max exactly 1.0. */
 int mrtx_upload_dem(mrtx_ctx* ctx, const float* host, int32_t h, int32_t w);
-/* Same, from a device pointer the caller owns (synthetic / device-built DEMs): the context
- * keeps the pointer, it does not copy.  Caller keeps it alive until destroy or re-upload. */
+/* Same, from a device pointer (synthetic / device-built DEMs).  Either way the context keeps its OWN copy,
+ * re-laid-out with a one-texel border (wrap in longitude, clamp in latitude) so a bilinear evaluation on
+ * the march path is two unconditional 8-byte loads; the caller may free its buffer when the call returns. */
 int mrtx_bind_dem_device(mrtx_ctx* ctx, const void* dev_f32, int32_t h, int32_t w);
 
 /* rt.set_texture_2d("moon_color", rgba_u8) + update_material("diffuse", {"ColorTextures": [...]})
@@ -175,9 +176,10 @@ int mrtx_dev_free(int32_t device, void* p);
 int mrtx_dev_download(int32_t device, void* host_dst, const void* dev_src, uint64_t bytes);
 int mrtx_dev_upload(int32_t device, void* dev_dst, const void* host_src, uint64_t bytes);
 
-/* Math conformance probe: evaluates the renderer's own atan2 / bilinear-address primitives on the
- * device for n inputs (tests compare them with the oracle bit for bit). */
-int mrtx_probe_atan2(int32_t device, const float* y, const float* x, float* out, int32_t n);
+/* Math conformance probe: evaluates the renderer's own (lat, lon) primitive -- polynomial atan2 pair sharing
+ * one reciprocal -- on the device for n moon-frame points (tests compare it with the oracle bit for bit). */
+int mrtx_probe_latlon(int32_t device, const float* a, const float* b, const float* c, float* lat, float* lon,
+                      int32_t n);
 
 #ifdef __cplusplus
 }

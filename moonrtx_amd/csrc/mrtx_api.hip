@@ -27,7 +27,9 @@ hipError_t mrtx_launch_ldem(const int16_t* src, float* dst, int h, int w, int d,
                             hipStream_t st);
 hipError_t mrtx_launch_synth_ldem(int16_t* dst, int h, int w, uint32_t seed, hipStream_t st);
 hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, hipStream_t st);
-hipError_t mrtx_launch_probe_atan2(const float* y, const float* x, float* out, int n, hipStream_t st);
+hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float* c, float* lat, float* lon, int n,
+                                    hipStream_t st);
+hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st);
 
 struct mrtx_ctx {
     MrtxConfig cfg{};
@@ -38,7 +40,7 @@ struct mrtx_ctx {
     float* accum = nullptr;
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
-    float* dem = nullptr; bool dem_owned = false; int dem_h = 0, dem_w = 0;
+    float* dem = nullptr; int dem_h = 0, dem_w = 0;   // padded (h+2) x (w+2) copy, always owned
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
     unsigned long long* stats_dev = nullptr;
@@ -163,6 +165,8 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     f.key0 = mix32h(c->prm.seed ^ 0x9E3779B9u);
     for (int i = 0; i < 3; i++) f.const_albedo[i] = c->prm.const_albedo[i];
     f.dem = c->dem; f.color = c->color; f.bg = c->bg;
+    f.dem_pitch = c->dem_w + 2;
+    f.dem_wide = ((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 2) * 4ull > 0xFFFFFFFFull) ? 1 : 0;
     f.tile_w = c->cfg.tile_w; f.tile_h = c->cfg.tile_h;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y;
     f.rank = c->cfg.rank; f.world = c->cfg.world; f.n_local_tiles = c->n_local;
@@ -239,7 +243,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->hits) (void)hipFree(c->hits);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
-    if (c->dem && c->dem_owned) (void)hipFree(c->dem);
+    if (c->dem) (void)hipFree(c->dem);
     if (c->color && c->color_owned) (void)hipFree(c->color);
     if (c->bg) (void)hipFree(c->bg);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -250,26 +254,34 @@ void mrtx_destroy(mrtx_ctx* c) {
 
 const char* mrtx_last_error(mrtx_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+// The context keeps its own PADDED copy of the DEM (see dem_march() in mrtx_kernels.hip).
+static int ingest_dem(mrtx_ctx* c, const float* dev_src, int32_t h, int32_t w) {
+    if (c->dem) { HIPCHK(c, hipFree(c->dem)); }
+    c->dem = nullptr; c->dem_h = c->dem_w = 0;
+    const size_t bytes = (size_t)(h + 2) * (size_t)(w + 2) * sizeof(float);
+    HIPCHK(c, hipMalloc((void**)&c->dem, bytes));
+    HIPCHK(c, mrtx_launch_pad_dem(dev_src, c->dem, h, w, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->dem_h = h; c->dem_w = w;
+    return MRTX_OK;
+}
 int mrtx_upload_dem(mrtx_ctx* c, const float* host, int32_t h, int32_t w) {
     if (!c) return MRTX_E_INVALID;
     if (!host || h < 2 || w < 2) return fail(c, MRTX_E_INVALID, "DEM must be a float32 (h>=2, w>=2) array");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->dem && c->dem_owned) { HIPCHK(c, hipFree(c->dem)); }
-    c->dem = nullptr; c->dem_owned = false;
+    float* stage = nullptr;
     const size_t bytes = (size_t)h * w * sizeof(float);
-    HIPCHK(c, hipMalloc((void**)&c->dem, bytes));
-    c->dem_owned = true;
-    HIPCHK(c, hipMemcpy(c->dem, host, bytes, hipMemcpyHostToDevice));
-    c->dem_h = h; c->dem_w = w;
-    return MRTX_OK;
+    HIPCHK(c, hipMalloc((void**)&stage, bytes));
+    hipError_t e = hipMemcpy(stage, host, bytes, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? ingest_dem(c, stage, h, w) : fail(c, MRTX_E_DEVICE, "hipMemcpy H2D: %s", hipGetErrorString(e));
+    (void)hipFree(stage);
+    return rc;
 }
 int mrtx_bind_dem_device(mrtx_ctx* c, const void* dev, int32_t h, int32_t w) {
     if (!c) return MRTX_E_INVALID;
     if (!dev || h < 2 || w < 2) return fail(c, MRTX_E_INVALID, "bad device DEM");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->dem && c->dem_owned) { HIPCHK(c, hipFree(c->dem)); }
-    c->dem = (float*)dev; c->dem_owned = false; c->dem_h = h; c->dem_w = w;
-    return MRTX_OK;
+    return ingest_dem(c, (const float*)dev, h, w);
 }
 int mrtx_upload_color(mrtx_ctx* c, const uint8_t* rgba, int32_t h, int32_t w) {
     if (!c) return MRTX_E_INVALID;
@@ -459,7 +471,7 @@ int mrtx_device_ptr(mrtx_ctx* c, int32_t which, void** out, uint64_t* bytes) {
     switch (which) {
         case MRTX_BUF_ACCUM: *out = c->accum; if (bytes) *bytes = fb; break;
         case MRTX_BUF_HITS: *out = c->hits; if (bytes) *bytes = fb; break;
-        case MRTX_BUF_DEM: *out = c->dem; if (bytes) *bytes = (uint64_t)c->dem_h * c->dem_w * 4; break;
+        case MRTX_BUF_DEM: *out = c->dem; if (bytes) *bytes = c->dem ? (uint64_t)(c->dem_h + 2) * (c->dem_w + 2) * 4 : 0; break;
         case MRTX_BUF_COLOR: *out = c->color; if (bytes) *bytes = (uint64_t)c->color_h * c->color_w * 4; break;
         default: return fail(c, MRTX_E_INVALID, "unknown buffer id %d", which);
     }
@@ -526,21 +538,24 @@ int mrtx_dev_upload(int32_t device, void* dev_dst, const void* host_src, uint64_
     if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
     return hipMemcpy(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice) == hipSuccess ? MRTX_OK : MRTX_E_DEVICE;
 }
-int mrtx_probe_atan2(int32_t device, const float* y, const float* x, float* out, int32_t n) {
-    if (!y || !x || !out || n < 1) return MRTX_E_INVALID;
+int mrtx_probe_latlon(int32_t device, const float* a, const float* b, const float* c, float* lat, float* lon,
+                      int32_t n) {
+    if (!a || !b || !c || !lat || !lon || n < 1) return MRTX_E_INVALID;
     if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
-    float *dy = nullptr, *dx = nullptr, *dout = nullptr;
-    const size_t b = (size_t)n * sizeof(float);
-    int rc = MRTX_E_DEVICE;
-    if (hipMalloc((void**)&dy, b) == hipSuccess && hipMalloc((void**)&dx, b) == hipSuccess &&
-        hipMalloc((void**)&dout, b) == hipSuccess && hipMemcpy(dy, y, b, hipMemcpyHostToDevice) == hipSuccess &&
-        hipMemcpy(dx, x, b, hipMemcpyHostToDevice) == hipSuccess &&
-        mrtx_launch_probe_atan2(dy, dx, dout, n, nullptr) == hipSuccess &&
-        hipMemcpy(out, dout, b, hipMemcpyDeviceToHost) == hipSuccess)
-        rc = MRTX_OK;
-    if (dy) (void)hipFree(dy);
-    if (dx) (void)hipFree(dx);
-    if (dout) (void)hipFree(dout);
+    float* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const float* in[3] = {a, b, c};
+    const size_t bytes = (size_t)n * sizeof(float);
+    int rc = MRTX_OK;
+    for (int i = 0; i < 5 && rc == MRTX_OK; i++)
+        if (hipMalloc((void**)&d[i], bytes) != hipSuccess) rc = MRTX_E_NOMEM;
+    for (int i = 0; i < 3 && rc == MRTX_OK; i++)
+        if (hipMemcpy(d[i], in[i], bytes, hipMemcpyHostToDevice) != hipSuccess) rc = MRTX_E_DEVICE;
+    if (rc == MRTX_OK && (mrtx_launch_probe_latlon(d[0], d[1], d[2], d[3], d[4], n, nullptr) != hipSuccess ||
+                          hipMemcpy(lat, d[3], bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+                          hipMemcpy(lon, d[4], bytes, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = MRTX_E_DEVICE;
+    for (int i = 0; i < 5; i++)
+        if (d[i]) (void)hipFree(d[i]);
     return rc;
 }
 

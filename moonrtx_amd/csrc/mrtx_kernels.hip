@@ -31,12 +31,8 @@ __device__ constexpr float kHalfPi = 1.57079637050628662f;
 
 enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_N };
 
-// atan(q) ~= q * P(q^2) on [0,1]; full-quadrant atan2 by reflection.  |err| <= 1.3e-7.
-__device__ __forceinline__ float atan2_poly(float y, float x) {
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = ax > ay ? ax : ay;
-    const float mn = ax > ay ? ay : ax;
-    const float q = (mx == 0.0f) ? 0.0f : mn / mx;
+// atan(q) ~= q * P(q^2) on [0,1], |err| <= 1.3e-7
+__device__ __forceinline__ float atan_poly(float q) {
     const float s = q * q;
     float p = -0.004054343327879906f;
     p = fmaf(p, s, 0.02186218835413456f);
@@ -46,11 +42,26 @@ __device__ __forceinline__ float atan2_poly(float y, float x) {
     p = fmaf(p, s, 0.19946560263633728f);
     p = fmaf(p, s, -0.33329859375953674f);
     p = fmaf(p, s, 0.9999993443489075f);
-    float r = p * q;
-    if (ay > ax) r = kHalfPi - r;
-    if (x < 0.0f) r = kPi - r;
-    if (y < 0.0f) r = -r;
-    return r;
+    return p * q;
+}
+
+// (a, b, c) with rho = sqrt(a^2+b^2) -> lat = atan2(c, rho), lon = atan2(a, b).  The two min/max ratios
+// share ONE correctly rounded reciprocal (a v_div_scale/v_rcp/fma/v_div_fixup chain is ~12 VALU).
+__device__ __forceinline__ void latlon(float a, float b, float c, float rho, float& lat, float& lon) {
+    const float aa = fabsf(a), ab = fabsf(b), ac = fabsf(c);
+    const float m1 = rho > ac ? rho : ac, n1 = rho > ac ? ac : rho;
+    const float m2 = ab > aa ? ab : aa, n2 = ab > aa ? aa : ab;
+    float den = m1 * m2;
+    den = den < 1.0e-37f ? 1.0e-37f : den;
+    const float t = 1.0f / den;
+    float r1 = atan_poly(n1 * (t * m2));
+    float r2 = atan_poly(n2 * (t * m1));
+    if (ac > rho) r1 = kHalfPi - r1;
+    if (c < 0.0f) r1 = -r1;
+    if (aa > ab) r2 = kHalfPi - r2;
+    if (b < 0.0f) r2 = kPi - r2;
+    if (a < 0.0f) r2 = -r2;
+    lat = r1; lon = r2;
 }
 
 // cos / sin of 2*pi*u, u in [0,1): quadrant split + polynomials on [0, pi/2)
@@ -87,56 +98,79 @@ __device__ __forceinline__ float u01(uint32_t key, uint32_t dim) {
     return (float)(r >> 8) * 5.9604644775390625e-08f;
 }
 
-struct Tap {
-    int64_t i00, i01, i10, i11;
-    float fr, fc;
-};
-
-// texel coordinates -> four taps; rows clamp, columns wrap at the +/-180 seam
-// (renderer_navigation.py:581-588)
-__device__ __forceinline__ Tap grid_tap(const GridC& g, float rowf, float colf) {
-    if (colf < 0.0f) colf += g.wf;
-    if (colf >= g.wf) colf -= g.wf;
-    const float rfl = floorf(rowf);
-    int32_t r0 = (int32_t)rfl;
-    r0 = r0 < 0 ? 0 : (r0 > g.h - 2 ? g.h - 2 : r0);
-    float fr = rowf - (float)r0;
-    fr = fr < 0.0f ? 0.0f : (fr > 1.0f ? 1.0f : fr);
-    const float cfl = floorf(colf);
-    int32_t c0 = (int32_t)cfl;
-    const float fc = colf - cfl;
-    if (c0 >= g.w) c0 -= g.w;
-    int32_t c1 = c0 + 1;
-    if (c1 >= g.w) c1 = 0;
-    const int64_t b0 = (int64_t)r0 * g.w, b1 = b0 + g.w;
-    Tap t;
-    t.i00 = b0 + c0; t.i01 = b0 + c1; t.i10 = b1 + c0; t.i11 = b1 + c1;
-    t.fr = fr; t.fc = fc;
-    return t;
-}
 __device__ __forceinline__ float lerp2(float e00, float e01, float e10, float e11, float fr, float fc) {
     const float top = fmaf(fc, e01 - e00, e00);
     const float bot = fmaf(fc, e11 - e10, e10);
     return fmaf(fr, bot - top, top);
 }
-__device__ __forceinline__ float dem_at(const float* __restrict__ dem, const GridC& g, float rowf, float colf) {
-    const Tap t = grid_tap(g, rowf, colf);
-    return lerp2(dem[t.i00], dem[t.i01], dem[t.i10], dem[t.i11], t.fr, t.fc);
+
+// Bilinear taps, floor() form of renderer_navigation.py:581-588: r0 = floor(row), c0 = floor(col); rows r0 and
+// r0+1 clamp to [0,h-1], columns c0 and c0+1 wrap into [0,w).
+//
+// The DEM lives in HBM PADDED by one texel on every side (row -1 = row 0, row h = row h-1, column -1 =
+// column w-1, column w = column 0; pitch = w+2), so on the march path -- where (row, col) come from a
+// (lat, lon) and floor() lands in [-1,h-1] x [-1,w-1] -- a bilinear evaluation is two unconditional 8-byte
+// loads, no clamp, no wrap, no seam branch.
+struct __attribute__((packed, aligned(4))) Pair { float x, y; };
+
+template <bool WIDE>
+__device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float colf) {
+    const float rfl = floorf(rowf), cfl = floorf(colf);
+    int r0 = (int)rfl, c0 = (int)cfl;
+    r0 = min(max(r0, -1), f.gd.h - 1);          // never active for a valid (lat, lon); keeps a NaN inside the array
+    c0 = min(max(c0, -1), f.gd.w - 1);
+    const float fr = rowf - rfl, fc = colf - cfl;
+    const char* p;
+    if (WIDE) p = reinterpret_cast<const char*>(f.dem) + ((int64_t)(r0 + 1) * f.dem_pitch + (c0 + 1)) * 4;
+    else p = reinterpret_cast<const char*>(f.dem) + (uint32_t)(((uint32_t)(r0 + 1) * (uint32_t)f.dem_pitch + (uint32_t)(c0 + 1)) * 4u);
+    const Pair t = *reinterpret_cast<const Pair*>(p);
+    const Pair u = *reinterpret_cast<const Pair*>(p + (size_t)f.dem_pitch * 4);
+    return lerp2(t.x, t.y, u.x, u.y, fr, fc);
+}
+
+struct Tap {
+    int32_t ra, rb, ca, cb;
+    float fr, fc;
+};
+__device__ __forceinline__ int32_t wrapc(int32_t c, int32_t w) {
+    if (c < 0) c += w;
+    if (c >= w) c -= w;
+    if (c < 0) c += w;
+    if (c >= w) c -= w;
+    return c;
+}
+// general form (normal estimation one texel either side of the hit; colour texture)
+__device__ __forceinline__ Tap grid_tap(const GridC& g, float rowf, float colf) {
+    const float rfl = floorf(rowf), cfl = floorf(colf);
+    int32_t r0 = (int32_t)rfl, c0 = (int32_t)cfl;
+    r0 = r0 < -1 ? -1 : (r0 > g.h - 1 ? g.h - 1 : r0);
+    c0 = c0 < -2 ? -2 : (c0 > g.w ? g.w : c0);
+    Tap t;
+    t.ra = r0 < 0 ? 0 : r0;
+    t.rb = r0 + 1 > g.h - 1 ? g.h - 1 : r0 + 1;
+    t.ca = wrapc(c0, g.w);
+    t.cb = wrapc(c0 + 1, g.w);
+    t.fr = rowf - rfl; t.fc = colf - cfl;
+    return t;
+}
+__device__ __forceinline__ float dem_at(const FrameC& f, float rowf, float colf) {
+    const Tap t = grid_tap(f.gd, rowf, colf);
+    const float* __restrict__ d = f.dem;
+    const int64_t a = (int64_t)(t.ra + 1) * f.dem_pitch + 1, b = (int64_t)(t.rb + 1) * f.dem_pitch + 1;
+    return lerp2(d[a + t.ca], d[a + t.cb], d[b + t.ca], d[b + t.cb], t.fr, t.fc);
 }
 
 // D2/D3: is the point (moon frame) at or below the displaced surface?  r^2 <= (R * D(lat,lon))^2
-template <bool STATS>
-__device__ __forceinline__ bool below_surface(const FrameC& f, float pa, float pb, float pc, uint32_t* cnt) {
+template <bool WIDE>
+__device__ __forceinline__ bool below_surface(const FrameC& f, float pa, float pb, float pc) {
     const float rho2 = fmaf(pb, pb, pa * pa);
     const float r2 = fmaf(pc, pc, rho2);
     const float rho = sqrtf(rho2);
-    const float lat = atan2_poly(pc, rho);
-    const float lon = atan2_poly(pa, pb);
+    float lat, lon;
+    latlon(pa, pb, pc, rho, lat, lon);
     const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
     const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
-    const float d = dem_at(f.dem, f.gd, rowf, colf);
-    if (STATS) cnt[ST_HEIGHT]++;
-    const float surf = f.Rf * d;
+    const float surf = f.Rf * dem_march<WIDE>(f, rowf, colf);
     return r2 <= surf * surf;
 }
 
@@ -145,7 +179,7 @@ struct SampleOut {
     float h0, h1, h2, h3;
 };
 
-template <bool STATS>
+template <bool STATS, bool WIDE>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
@@ -190,21 +224,32 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         db = (float)((f.M[1][0] * Dx + f.M[1][1] * Dy) + f.M[1][2] * Dz);
         dc = (float)((f.M[2][0] * Dx + f.M[2][1] * Dy) + f.M[2][2] * Dz);
         const float smax = (float)(t1 - t0);
+        // coarse march: one exit test per trip (the wave leaves when no lane is still marching)
         float hi = 0.0f;
-        for (int k = 1; k <= f.kmax; k++) {
+        int k = 0;
+        bool go = true;
+        while (go) {
+            k++;
             const float sk = (float)k * f.step;
-            if (sk > smax) break;
-            if (below_surface<STATS>(f, fmaf(sk, da, pa), fmaf(sk, db, pb), fmaf(sk, dc, pc), cnt)) {
-                hit = true; hi = sk; lo = (float)(k - 1) * f.step;
-                break;
+            const bool in = (sk <= smax) & (k <= f.kmax);
+            bool bel = false;
+            if (in) {
+                bel = below_surface<WIDE>(f, fmaf(sk, da, pa), fmaf(sk, db, pb), fmaf(sk, dc, pc));
+                if (STATS) cnt[ST_HEIGHT]++;
             }
+            hit = bel;
+            hi = sk;
+            go = in & !bel;
         }
         if (hit) {
+            lo = (float)(k - 1) * f.step;
             for (int i = 0; i < f.nbis; i++) {
                 const float mid = 0.5f * (lo + hi);
-                if (below_surface<STATS>(f, fmaf(mid, da, pa), fmaf(mid, db, pb), fmaf(mid, dc, pc), cnt)) hi = mid;
-                else lo = mid;
+                const bool bel = below_surface<WIDE>(f, fmaf(mid, da, pa), fmaf(mid, db, pb), fmaf(mid, dc, pc));
+                hi = bel ? mid : hi;
+                lo = bel ? lo : mid;
             }
+            if (STATS) cnt[ST_HEIGHT] += (uint32_t)f.nbis;
         }
     }
 
@@ -224,9 +269,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
             }
         }
         if (f.bg) {  // D7
-            const float rho = sqrtf(fmaf(dy, dy, dx * dx));
-            const float el = atan2_poly(dz, rho);
-            const float az = atan2_poly(dx, dy);
+            float el, az;
+            latlon(dx, dy, dz, sqrtf(fmaf(dy, dy, dx * dx)), el, az);
             const float rowf = fmaf(el, f.bg_row_scale, f.bg_row_off);
             const float colf = fmaf(az, f.bg_col_scale, f.bg_col_off);
             int r = (int)floorf(rowf), c = (int)floorf(colf);
@@ -249,14 +293,14 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     const float r2 = fmaf(hc, hc, rho2);
     const float rho = sqrtf(rho2);
     const float r = sqrtf(r2);
-    const float lat = atan2_poly(hc, rho);
-    const float lon = atan2_poly(ha, hb);
+    float lat, lon;
+    latlon(ha, hb, hc, rho, lat, lon);
     const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
     const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
-    const float dn = dem_at(f.dem, f.gd, rowf - 1.0f, colf);
-    const float ds = dem_at(f.dem, f.gd, rowf + 1.0f, colf);
-    const float de = dem_at(f.dem, f.gd, rowf, colf + 1.0f);
-    const float dw = dem_at(f.dem, f.gd, rowf, colf - 1.0f);
+    const float dn = dem_at(f, rowf - 1.0f, colf);
+    const float ds = dem_at(f, rowf + 1.0f, colf);
+    const float de = dem_at(f, rowf, colf + 1.0f);
+    const float dw = dem_at(f, rowf, colf - 1.0f);
     if (STATS) cnt[ST_HEIGHT] += 4;
     const float dlat = (dn - ds) * f.dlat_scale;
     const float dlon = (de - dw) * f.dlon_scale;
@@ -278,7 +322,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         const float cc = fmaf(lon, f.gc.col_scale, f.gc.col_off);
         const Tap t = grid_tap(f.gc, rc, cc);
         const uint32_t* tex = reinterpret_cast<const uint32_t*>(f.color);
-        const uint32_t p00 = tex[t.i00], p01 = tex[t.i01], p10 = tex[t.i10], p11 = tex[t.i11];
+        const int64_t ra = (int64_t)t.ra * f.gc.w, rb = (int64_t)t.rb * f.gc.w;
+        const uint32_t p00 = tex[ra + t.ca], p01 = tex[ra + t.cb], p10 = tex[rb + t.ca], p11 = tex[rb + t.cb];
         al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), t.fr, t.fc) / 255.0f;
         al1 = lerp2((float)((p00 >> 8) & 255u), (float)((p01 >> 8) & 255u), (float)((p10 >> 8) & 255u),
                     (float)((p11 >> 8) & 255u), t.fr, t.fc) / 255.0f;
@@ -324,15 +369,26 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     if (!(cosi > 0.0f)) return;
 
     if (STATS) cnt[ST_SHADOW]++;
-    bool lit = true;
-    for (int k = 1; k <= f.kmax; k++) {
-        const float sk = (float)k * f.step;
-        const float qa = fmaf(sk, wa, oa), qb = fmaf(sk, wb, ob), qc = fmaf(sk, wc, oc);
-        const float q2 = fmaf(qc, qc, fmaf(qb, qb, qa * qa));
-        if (q2 > f.R2f) break;
-        if (below_surface<STATS>(f, qa, qb, qc, cnt)) { lit = false; break; }
+    bool occluded = false;
+    {
+        int k = 0;
+        bool go = true;
+        while (go) {
+            k++;
+            const float sk = (float)k * f.step;
+            const float qa = fmaf(sk, wa, oa), qb = fmaf(sk, wb, ob), qc = fmaf(sk, wc, oc);
+            const float q2 = fmaf(qc, qc, fmaf(qb, qb, qa * qa));
+            const bool in = (q2 <= f.R2f) & (k <= f.kmax);
+            bool bel = false;
+            if (in) {
+                bel = below_surface<WIDE>(f, qa, qb, qc);
+                if (STATS) cnt[ST_HEIGHT]++;
+            }
+            occluded = bel;
+            go = in & !bel;
+        }
     }
-    if (!lit) return;
+    if (occluded) return;
     const float wgt = (f.rad2 * omc) * cosi;
     o.c0 = al0 * wgt; o.c1 = al1 * wgt; o.c2 = al2 * wgt;
 }
@@ -346,7 +402,7 @@ __device__ __forceinline__ float tree_sum(float v) {
 
 // One wave = 64 (pixel, sample) pairs: P = 64/S pixels (PW x PH block) x S samples in adjacent lanes.
 // One 256-thread workgroup = one 16x16-pixel sub-tile of a sharding tile.
-template <int S, bool STATS>
+template <int S, bool STATS, bool WIDE>
 __global__ void __launch_bounds__(256) render_kernel(const FrameC f) {
     constexpr int P = 64 / S;
     constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;
@@ -391,7 +447,7 @@ __global__ void __launch_bounds__(256) render_kernel(const FrameC f) {
         o.h0 = o.h1 = o.h2 = o.h3 = 0.f;
         for (uint32_t blk = 0; blk < f.n_blocks; blk++) {
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
-            if (inb) trace_sample<STATS>(f, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            if (inb) trace_sample<STATS, WIDE>(f, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
             s0 += tree_sum<S>(o.c0);
             s1 += tree_sum<S>(o.c1);
             s2 += tree_sum<S>(o.c2);
@@ -621,9 +677,21 @@ __global__ void synth_color_kernel(uint32_t* __restrict__ dst, int h, int w, uin
     }
 }
 
-__global__ void probe_atan2_kernel(const float* y, const float* x, float* out, int n) {
+__global__ void probe_latlon_kernel(const float* a, const float* b, const float* c, float* lat, float* lon, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = atan2_poly(y[i], x[i]);
+    if (i < n) latlon(a[i], b[i], c[i], sqrtf(fmaf(b[i], b[i], a[i] * a[i])), lat[i], lon[i]);
+}
+
+// DEM (h, w) row-major -> padded (h+2, w+2): row -1 = row 0, row h = row h-1, col -1 = col w-1, col w = col 0
+__global__ void pad_dem_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w) {
+    const int pitch = w + 2;
+    const int64_t n = (int64_t)(h + 2) * pitch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / pitch) - 1, c = (int)(i % pitch) - 1;
+        r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+        c = c < 0 ? w - 1 : (c > w - 1 ? 0 : c);
+        dst[i] = src[(int64_t)r * w + c];
+    }
 }
 
 }  // namespace mrtx
@@ -636,16 +704,19 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, hipStream_t st
     const int groups = (f.n_local_tiles + 7) / 8;
     const dim3 grid((unsigned)(groups * subs * 8)), block(256);
     if (grid.x == 0) return hipSuccess;
-#define MRTX_CASE(SV)                                                                          \
-    case SV:                                                                                   \
-        if (stats) hipLaunchKernelGGL((mrtx::render_kernel<SV, true>), grid, block, 0, st, f); \
-        else hipLaunchKernelGGL((mrtx::render_kernel<SV, false>), grid, block, 0, st, f);      \
+    const bool wide = f.dem_wide != 0;
+#define MRTX_LAUNCH(SV, ST, WD) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD>), grid, block, 0, st, f)
+#define MRTX_CASE(SV)                                                  \
+    case SV:                                                           \
+        if (wide) { if (stats) MRTX_LAUNCH(SV, true, true); else MRTX_LAUNCH(SV, false, true); }   \
+        else { if (stats) MRTX_LAUNCH(SV, true, false); else MRTX_LAUNCH(SV, false, false); }      \
         break;
     switch (S) {
         MRTX_CASE(1) MRTX_CASE(2) MRTX_CASE(4) MRTX_CASE(8) MRTX_CASE(16) MRTX_CASE(32) MRTX_CASE(64)
         default: return hipErrorInvalidValue;
     }
 #undef MRTX_CASE
+#undef MRTX_LAUNCH
     return hipGetLastError();
 }
 
@@ -697,8 +768,13 @@ hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, h
     hipLaunchKernelGGL(mrtx::synth_color_kernel, dim3(grid_for((int64_t)h * w)), dim3(256), 0, st, dst, h, w, seed);
     return hipGetLastError();
 }
-hipError_t mrtx_launch_probe_atan2(const float* y, const float* x, float* out, int n, hipStream_t st) {
-    hipLaunchKernelGGL(mrtx::probe_atan2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, y, x, out, n);
+hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float* c, float* lat, float* lon, int n,
+                                    hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::probe_latlon_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, lat, lon, n);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::pad_dem_kernel, dim3(grid_for((int64_t)(h + 2) * (w + 2))), dim3(256), 0, st, src, dst, h, w);
     return hipGetLastError();
 }
 }

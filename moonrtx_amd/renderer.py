@@ -103,8 +103,8 @@ class MoonRT:
         self._keepalive.pop("dem", None)
 
     def bind_dem(self, buf, h, w):
+        """Ingest a device-resident float32 (h, w) DEM; the context makes its own padded copy."""
         self._check(self._lib.mrtx_bind_dem_device(self._ctx, buf.ptr, h, w), "mrtx_bind_dem_device")
-        self._keepalive["dem"] = buf
 
     def upload_color(self, rgba):
         if rgba is None:
@@ -252,12 +252,13 @@ def dem_from_ldem(src_buf, h, w, downscale=1, device=0):
     return dst, float(scale.value)
 
 
-def probe_atan2(y, x, device=0):
+def probe_latlon(a, b, c, device=0):
+    """Device evaluation of the renderer's (lat, lon) primitive for moon-frame points (a, b, c)."""
     lib = _lib.load()
-    y = np.ascontiguousarray(y, np.float32).ravel()
-    x = np.ascontiguousarray(x, np.float32).ravel()
-    out = np.empty_like(y)
-    rc = lib.mrtx_probe_atan2(device, y.ctypes.data, x.ctypes.data, out.ctypes.data, y.size)
+    a, b, c = (np.ascontiguousarray(v, np.float32).ravel() for v in (a, b, c))
+    lat = np.empty_like(a); lon = np.empty_like(a)
+    rc = lib.mrtx_probe_latlon(device, a.ctypes.data, b.ctypes.data, c.ctypes.data, lat.ctypes.data,
+                               lon.ctypes.data, a.size)
     if rc != 0:
-        raise MoonRTError(f"mrtx_probe_atan2 failed ({rc})")
-    return out
+        raise MoonRTError(f"mrtx_probe_latlon failed ({rc})")
+    return lat, lon

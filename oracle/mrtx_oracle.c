@@ -71,11 +71,7 @@ static const float SN0 = 1.0f, SN1 = -0.16666647791862488f, SN2 = 0.008332899771
 static const float CS0 = 0.9999999403953552f, CS1 = -0.4999990463256836f, CS2 = 0.04166358336806297f,
                    CS3 = -0.001385370153002441f, CS4 = 2.3153859729063697e-05f;
 
-float orc_atan2f(float y, float x) {
-    float ax = fabsf(x), ay = fabsf(y);
-    float mx = ax > ay ? ax : ay;
-    float mn = ax > ay ? ay : ax;
-    float q = (mx == 0.0f) ? 0.0f : mn / mx;
+static inline float atan_poly(float q) {
     float s = q * q;
     float p = AT7;
     p = fmaf(p, s, AT6);
@@ -85,11 +81,27 @@ float orc_atan2f(float y, float x) {
     p = fmaf(p, s, AT2);
     p = fmaf(p, s, AT1);
     p = fmaf(p, s, AT0);
-    float r = p * q;
-    if (ay > ax) r = HALF_PI_F - r;
-    if (x < 0.0f) r = PI_F - r;
-    if (y < 0.0f) r = -r;
-    return r;
+    return p * q;
+}
+
+/* (a, b, c) -> lat = atan2(c, sqrt(a^2+b^2)), lon = atan2(a, b).  Both min/max ratios come from ONE
+ * reciprocal: t = 1/(m1*m2), q1 = n1*(t*m2), q2 = n2*(t*m1). */
+void orc_latlon(float a, float b, float c, float* lat, float* lon) {
+    float rho = sqrtf(fmaf(b, b, a * a));
+    float aa = fabsf(a), ab = fabsf(b), ac = fabsf(c);
+    float m1 = rho > ac ? rho : ac, n1 = rho > ac ? ac : rho;
+    float m2 = ab > aa ? ab : aa, n2 = ab > aa ? aa : ab;
+    float den = m1 * m2;
+    den = den < 1.0e-37f ? 1.0e-37f : den;
+    float t = 1.0f / den;
+    float r1 = atan_poly(n1 * (t * m2));
+    float r2 = atan_poly(n2 * (t * m1));
+    if (ac > rho) r1 = HALF_PI_F - r1;
+    if (c < 0.0f) r1 = -r1;
+    if (aa > ab) r2 = HALF_PI_F - r2;
+    if (b < 0.0f) r2 = PI_F - r2;
+    if (a < 0.0f) r2 = -r2;
+    *lat = r1; *lon = r2;
 }
 
 static inline void sincos_quadrant(float u, float* cs, float* sn) {
@@ -145,24 +157,26 @@ static void grid_init(Grid* g, int32_t h, int32_t w) {
 
 typedef struct Tap { int64_t i00, i01, i10, i11; float fr, fc; } Tap;
 
-/* texel coordinates -> the four taps; rows clamp, columns wrap (renderer_navigation.py:581-588) */
+/* texel coordinates -> the four taps (renderer_navigation.py:581-588 restated on floor()):
+ * r0 = floor(row), fr = row - r0, rows r0 and r0+1 each clamped to [0, h-1]  (row -1 == row 0, row h == row h-1)
+ * c0 = floor(col), fc = col - c0, columns c0 and c0+1 wrapped into [0, w)      (col -1 == col w-1, col w == col 0) */
+static inline int32_t wrapc(int32_t c, int32_t w) {
+    if (c < 0) c += w;
+    if (c >= w) c -= w;
+    if (c < 0) c += w;
+    if (c >= w) c -= w;
+    return c;
+}
 static inline void grid_tap(const Grid* g, float rowf, float colf, Tap* t) {
-    if (colf < 0.0f) colf += g->wf;
-    if (colf >= g->wf) colf -= g->wf;
-    float rfl = floorf(rowf);
-    int32_t r0 = (int32_t)rfl;
-    r0 = r0 < 0 ? 0 : (r0 > g->h - 2 ? g->h - 2 : r0);
-    float fr = rowf - (float)r0;
-    fr = fr < 0.0f ? 0.0f : (fr > 1.0f ? 1.0f : fr);
-    float cfl = floorf(colf);
-    int32_t c0 = (int32_t)cfl;
-    float fc = colf - cfl;
-    if (c0 >= g->w) c0 -= g->w;
-    int32_t c1 = c0 + 1;
-    if (c1 >= g->w) c1 = 0;
-    int64_t b0 = (int64_t)r0 * g->w, b1 = b0 + g->w;
-    t->i00 = b0 + c0; t->i01 = b0 + c1; t->i10 = b1 + c0; t->i11 = b1 + c1;
-    t->fr = fr; t->fc = fc;
+    float rfl = floorf(rowf), cfl = floorf(colf);
+    int32_t r0 = (int32_t)rfl, c0 = (int32_t)cfl;
+    r0 = r0 < -1 ? -1 : (r0 > g->h - 1 ? g->h - 1 : r0);
+    c0 = c0 < -2 ? -2 : (c0 > g->w ? g->w : c0);
+    int32_t ra = r0 < 0 ? 0 : r0, rb = r0 + 1 > g->h - 1 ? g->h - 1 : r0 + 1;
+    int32_t ca = wrapc(c0, g->w), cb = wrapc(c0 + 1, g->w);
+    t->i00 = (int64_t)ra * g->w + ca; t->i01 = (int64_t)ra * g->w + cb;
+    t->i10 = (int64_t)rb * g->w + ca; t->i11 = (int64_t)rb * g->w + cb;
+    t->fr = rowf - rfl; t->fc = colf - cfl;
 }
 static inline void grid_rc(const Grid* g, float lat, float lon, float* rowf, float* colf) {
     *rowf = fmaf(lat, g->row_scale, g->row_off);
@@ -294,9 +308,8 @@ static inline int below_surface(const OrcScene* s, const Frame* f, float pa, flo
                                 uint64_t* st) {
     float rho2 = fmaf(pb, pb, pa * pa);
     float r2 = fmaf(pc, pc, rho2);
-    float rho = sqrtf(rho2);
-    float lat = orc_atan2f(pc, rho);
-    float lon = orc_atan2f(pa, pb);
+    float lat, lon;
+    orc_latlon(pa, pb, pc, &lat, &lon);
     float rowf, colf;
     grid_rc(&f->gd, lat, lon, &rowf, &colf);
     float d = dem_at(s->dem, &f->gd, rowf, colf);
@@ -387,9 +400,8 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
             }
         }
         if (s->bg) {
-            float rho = sqrtf(fmaf(dy, dy, dx * dx));
-            float el = orc_atan2f(dz, rho);
-            float az = orc_atan2f(dx, dy);
+            float el, az;
+            orc_latlon(dx, dy, dz, &el, &az);
             float rowf = fmaf(el, f->bg_row_scale, f->bg_row_off);
             float colf = fmaf(az, f->bg_col_scale, f->bg_col_off);
             int r = (int)floorf(rowf), c = (int)floorf(colf);
@@ -412,8 +424,8 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
     float r2 = fmaf(hc, hc, rho2);
     float rho = sqrtf(rho2);
     float r = sqrtf(r2);
-    float lat = orc_atan2f(hc, rho);
-    float lon = orc_atan2f(ha, hb);
+    float lat, lon;
+    orc_latlon(ha, hb, hc, &lat, &lon);
     float rowf, colf;
     grid_rc(&f->gd, lat, lon, &rowf, &colf);
     float dn = dem_at(s->dem, &f->gd, rowf - 1.0f, colf);

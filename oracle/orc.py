@@ -62,8 +62,8 @@ def lib():
         build()
         name = "liborc_fma.so" if _has_fma() else "liborc_soft.so"
         L = C.CDLL(os.path.join(_HERE, name))
-        L.orc_atan2f.restype = C.c_float
-        L.orc_atan2f.argtypes = [C.c_float, C.c_float]
+        L.orc_latlon.restype = None
+        L.orc_latlon.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_dem_bilinear.restype = C.c_float
         L.orc_dem_bilinear.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float]
         L.orc_render.restype = C.c_int
@@ -88,11 +88,16 @@ def set_threads(n):
     return int(lib().orc_set_threads(int(n)))
 
 
-def atan2f(y, x):
+def latlon(a, b, c):
+    """The spec's (lat, lon) of a moon-frame point, element-wise (float32 arrays in, two arrays out)."""
     L = lib()
-    y = np.asarray(y, np.float32).ravel()
-    x = np.asarray(x, np.float32).ravel()
-    return np.array([L.orc_atan2f(float(a), float(b)) for a, b in zip(y, x)], np.float32)
+    a, b, c = (np.asarray(v, np.float32).ravel() for v in (a, b, c))
+    lat = np.empty_like(a); lon = np.empty_like(a)
+    la, lo = C.c_float(), C.c_float()
+    for i in range(a.size):
+        L.orc_latlon(float(a[i]), float(b[i]), float(c[i]), C.byref(la), C.byref(lo))
+        lat[i] = la.value; lon[i] = lo.value
+    return lat, lon
 
 
 def dem_bilinear(dem, lat_rad, lon_rad):

@@ -36,12 +36,18 @@ def check(scene, dem, color=None, bg=None, blocks=(1,)):
 
 def test_math_primitives_bit_exact(native_lib):
     rng = np.random.default_rng(3)
-    y = np.concatenate([rng.standard_normal(20000), [0, 0, 1, -1, 0.0, 1e-30, -1e-30, 3.0]]).astype(np.float32)
-    x = np.concatenate([rng.standard_normal(20000), [0, 1, 0, 0, -1.0, 1e-30, 1e-30, -3.0]]).astype(np.float32)
-    dev = renderer.probe_atan2(y, x)
-    ref = orc.atan2f(y, x)
-    assert_bit_equal(dev, ref, "atan2 polynomial")
-    assert np.abs(ref.astype(np.float64) - np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() < 4e-7
+    n = 20000
+    pts = rng.standard_normal((n, 3)).astype(np.float32) * 10
+    special = np.array([[0, 0, 10], [0, 0, -10], [0, 10, 0], [0, -10, 0], [10, 0, 0], [-10, 0, 0], [0, 0, 0],
+                        [1e-30, 0, 1], [0, 1e-30, -1], [1e-20, -1e-20, 5], [3, -3, 3], [-7, -7, 0]], np.float32)
+    pts = np.concatenate([pts, special])
+    lat_d, lon_d = renderer.probe_latlon(pts[:, 0], pts[:, 1], pts[:, 2])
+    lat_o, lon_o = orc.latlon(pts[:, 0], pts[:, 1], pts[:, 2])
+    assert_bit_equal(lat_d, lat_o, "lat polynomial")
+    assert_bit_equal(lon_d, lon_o, "lon polynomial")
+    p64 = pts[:n].astype(np.float64)
+    assert np.abs(lat_o[:n] - np.arctan2(p64[:, 2], np.hypot(p64[:, 0], p64[:, 1]))).max() < 6e-7
+    assert np.abs(lon_o[:n] - np.arctan2(p64[:, 0], p64[:, 1])).max() < 6e-7
 
 
 @pytest.mark.parametrize("name", ["S1", "S2", "S3"])
