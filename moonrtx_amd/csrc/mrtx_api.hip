@@ -166,6 +166,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     for (int i = 0; i < 3; i++) f.const_albedo[i] = c->prm.const_albedo[i];
     f.dem = c->dem; f.color = c->color; f.bg = c->bg;
     f.dem_pitch = c->dem_w + 2;
+    f.dem_maxidx = (uint32_t)((uint64_t)c->dem_h * (uint64_t)(c->dem_w + 2) + (uint64_t)c->dem_w);
     f.dem_wide = ((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 2) * 4ull > 0xFFFFFFFFull) ? 1 : 0;
     f.tile_w = c->cfg.tile_w; f.tile_h = c->cfg.tile_h;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y;

@@ -36,6 +36,7 @@ struct FrameC {
     float const_albedo[3];
     const float* dem;       // PADDED (h+2) x (w+2): element [0] is (row -1, col -1); see dem_march()
     int32_t dem_pitch, dem_wide;   // pitch = w+2 floats; wide = byte offsets need 64 bits (> 4 GiB)
+    uint32_t dem_maxidx;           // h*pitch + w: last padded index a 2x2 tap may start at
     const uint8_t* color;   // RGBA8 or null
     const uint8_t* bg;      // RGBA8 or null
     // image-tile sharding (new) + accumulation state

@@ -45,23 +45,37 @@ __device__ __forceinline__ float atan_poly(float q) {
     return p * q;
 }
 
-// (a, b, c) with rho = sqrt(a^2+b^2) -> lat = atan2(c, rho), lon = atan2(a, b).  The two min/max ratios
-// share ONE correctly rounded reciprocal (a v_div_scale/v_rcp/fma/v_div_fixup chain is ~12 VALU).
-__device__ __forceinline__ void latlon(float a, float b, float c, float rho, float& lat, float& lon) {
+// Correctly rounded sqrt for x in [2^-96, 2^96]: the raw v_sqrt_f32 (<= 1 ulp) plus the +-1 ulp residual
+// test LLVM uses, without the denormal pre-scaling and class checks the general expansion carries
+// (callers clamp x into the domain; tests compare against the host's IEEE sqrtf bit for bit).
+__device__ __forceinline__ float sqrt_cr(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = fmaf(-s_dn, s, x);
+    const float r_up = fmaf(-s_up, s, x);
+    s = r_dn <= 0.0f ? s_dn : s;
+    s = r_up > 0.0f ? s_up : s;
+    return s;
+}
+
+// (a, b, c) -> lat = atan2(c, rho), lon = atan2(a, b), rho = sqrt(max(a^2+b^2, 1e-28)).  The two min/max
+// ratios share ONE correctly rounded reciprocal (a v_div_scale/v_rcp/fma/v_div_fixup chain is ~12 VALU);
+// min/max instead of compare+select keeps VCC hazards (s_nop) out of the loop.
+__device__ __forceinline__ void latlon(float a, float b, float c, float rho2, float& lat, float& lon) {
+    const float rho = sqrt_cr(fmaxf(rho2, 1.0e-28f));
     const float aa = fabsf(a), ab = fabsf(b), ac = fabsf(c);
-    const float m1 = rho > ac ? rho : ac, n1 = rho > ac ? ac : rho;
-    const float m2 = ab > aa ? ab : aa, n2 = ab > aa ? aa : ab;
-    float den = m1 * m2;
-    den = den < 1.0e-37f ? 1.0e-37f : den;
+    const float m1 = fmaxf(rho, ac), n1 = fminf(rho, ac);
+    const float m2 = fmaxf(ab, aa), n2 = fminf(ab, aa);
+    const float den = fmaxf(m1 * m2, 1.0e-37f);
     const float t = 1.0f / den;
     float r1 = atan_poly(n1 * (t * m2));
     float r2 = atan_poly(n2 * (t * m1));
-    if (ac > rho) r1 = kHalfPi - r1;
-    if (c < 0.0f) r1 = -r1;
-    if (aa > ab) r2 = kHalfPi - r2;
-    if (b < 0.0f) r2 = kPi - r2;
-    if (a < 0.0f) r2 = -r2;
-    lat = r1; lon = r2;
+    r1 = ac >= rho ? kHalfPi - r1 : r1;
+    r2 = aa >= ab ? kHalfPi - r2 : r2;
+    r2 = b < 0.0f ? kPi - r2 : r2;
+    lat = copysignf(r1, c);
+    lon = copysignf(r2, a);
 }
 
 // cos / sin of 2*pi*u, u in [0,1): quadrant split + polynomials on [0, pi/2)
@@ -116,15 +130,22 @@ struct __attribute__((packed, aligned(4))) Pair { float x, y; };
 template <bool WIDE>
 __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float colf) {
     const float rfl = floorf(rowf), cfl = floorf(colf);
-    int r0 = (int)rfl, c0 = (int)cfl;
-    r0 = min(max(r0, -1), f.gd.h - 1);          // never active for a valid (lat, lon); keeps a NaN inside the array
-    c0 = min(max(c0, -1), f.gd.w - 1);
     const float fr = rowf - rfl, fc = colf - cfl;
-    const char* p;
-    if (WIDE) p = reinterpret_cast<const char*>(f.dem) + ((int64_t)(r0 + 1) * f.dem_pitch + (c0 + 1)) * 4;
-    else p = reinterpret_cast<const char*>(f.dem) + (uint32_t)(((uint32_t)(r0 + 1) * (uint32_t)f.dem_pitch + (uint32_t)(c0 + 1)) * 4u);
-    const Pair t = *reinterpret_cast<const Pair*>(p);
-    const Pair u = *reinterpret_cast<const Pair*>(p + (size_t)f.dem_pitch * 4);
+    // padded index of (r0, c0) = (r0+1)*pitch + (c0+1); both factors < 2^24 -> one v_mad_u32_u24.  A single
+    // unsigned min keeps any garbage (NaN position) inside the array; it never bites for a valid (lat, lon).
+    const uint32_t r0p = (uint32_t)((int)rfl + 1), c0p = (uint32_t)((int)cfl + 1);
+    const uint32_t idx = min(__umul24(r0p, (uint32_t)f.dem_pitch) + c0p, f.dem_maxidx);
+    const char* base = reinterpret_cast<const char*>(f.dem);
+    Pair t, u;
+    if (WIDE) {
+        const char* p = base + ((uint64_t)idx << 2);
+        t = *reinterpret_cast<const Pair*>(p);
+        u = *reinterpret_cast<const Pair*>(p + ((uint64_t)(uint32_t)f.dem_pitch << 2));
+    } else {
+        const uint32_t off0 = idx << 2, off1 = off0 + ((uint32_t)f.dem_pitch << 2);
+        t = *reinterpret_cast<const Pair*>(base + off0);
+        u = *reinterpret_cast<const Pair*>(base + off1);
+    }
     return lerp2(t.x, t.y, u.x, u.y, fr, fc);
 }
 
@@ -165,9 +186,8 @@ template <bool WIDE>
 __device__ __forceinline__ bool below_surface(const FrameC& f, float pa, float pb, float pc) {
     const float rho2 = fmaf(pb, pb, pa * pa);
     const float r2 = fmaf(pc, pc, rho2);
-    const float rho = sqrtf(rho2);
     float lat, lon;
-    latlon(pa, pb, pc, rho, lat, lon);
+    latlon(pa, pb, pc, rho2, lat, lon);
     const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
     const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
     const float surf = f.Rf * dem_march<WIDE>(f, rowf, colf);
@@ -270,7 +290,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         }
         if (f.bg) {  // D7
             float el, az;
-            latlon(dx, dy, dz, sqrtf(fmaf(dy, dy, dx * dx)), el, az);
+            latlon(dx, dy, dz, fmaf(dy, dy, dx * dx), el, az);
             const float rowf = fmaf(el, f.bg_row_scale, f.bg_row_off);
             const float colf = fmaf(az, f.bg_col_scale, f.bg_col_off);
             int r = (int)floorf(rowf), c = (int)floorf(colf);
@@ -294,7 +314,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     const float rho = sqrtf(rho2);
     const float r = sqrtf(r2);
     float lat, lon;
-    latlon(ha, hb, hc, rho, lat, lon);
+    latlon(ha, hb, hc, rho2, lat, lon);
     const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
     const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
     const float dn = dem_at(f, rowf - 1.0f, colf);
@@ -679,7 +699,7 @@ __global__ void synth_color_kernel(uint32_t* __restrict__ dst, int h, int w, uin
 
 __global__ void probe_latlon_kernel(const float* a, const float* b, const float* c, float* lat, float* lon, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) latlon(a[i], b[i], c[i], sqrtf(fmaf(b[i], b[i], a[i] * a[i])), lat[i], lon[i]);
+    if (i < n) latlon(a[i], b[i], c[i], fmaf(b[i], b[i], a[i] * a[i]), lat[i], lon[i]);
 }
 
 // DEM (h, w) row-major -> padded (h+2, w+2): row -1 = row 0, row h = row h-1, col -1 = col w-1, col w = col 0

@@ -84,10 +84,13 @@ static inline float atan_poly(float q) {
     return p * q;
 }
 
-/* (a, b, c) -> lat = atan2(c, sqrt(a^2+b^2)), lon = atan2(a, b).  Both min/max ratios come from ONE
- * reciprocal: t = 1/(m1*m2), q1 = n1*(t*m2), q2 = n2*(t*m1). */
+/* (a, b, c) -> lat = atan2(c, rho), lon = atan2(a, b), rho = sqrt(max(a^2+b^2, 1e-28)).
+ * Both min/max ratios come from ONE reciprocal: t = 1/(m1*m2), q1 = n1*(t*m2), q2 = n2*(t*m1).
+ * Octant reflection when the "y" magnitude is >= the "x" magnitude; signs copied from c and a. */
 void orc_latlon(float a, float b, float c, float* lat, float* lon) {
-    float rho = sqrtf(fmaf(b, b, a * a));
+    float rho2 = fmaf(b, b, a * a);
+    rho2 = rho2 < 1.0e-28f ? 1.0e-28f : rho2;
+    float rho = sqrtf(rho2);
     float aa = fabsf(a), ab = fabsf(b), ac = fabsf(c);
     float m1 = rho > ac ? rho : ac, n1 = rho > ac ? ac : rho;
     float m2 = ab > aa ? ab : aa, n2 = ab > aa ? aa : ab;
@@ -96,12 +99,11 @@ void orc_latlon(float a, float b, float c, float* lat, float* lon) {
     float t = 1.0f / den;
     float r1 = atan_poly(n1 * (t * m2));
     float r2 = atan_poly(n2 * (t * m1));
-    if (ac > rho) r1 = HALF_PI_F - r1;
-    if (c < 0.0f) r1 = -r1;
-    if (aa > ab) r2 = HALF_PI_F - r2;
+    if (ac >= rho) r1 = HALF_PI_F - r1;
+    if (aa >= ab) r2 = HALF_PI_F - r2;
     if (b < 0.0f) r2 = PI_F - r2;
-    if (a < 0.0f) r2 = -r2;
-    *lat = r1; *lon = r2;
+    *lat = copysignf(r1, c);
+    *lon = copysignf(r2, a);
 }
 
 static inline void sincos_quadrant(float u, float* cs, float* sn) {
