@@ -151,6 +151,10 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     f.nbis = 0;
     for (double wdt = (double)f.step; wdt > (double)f.eps && f.nbis < 24; wdt *= 0.5) f.nbis++;
     f.kmax = (int)(2.0 * c->radius / (double)f.step) + 8;
+    f.inv_step = 1.0f / f.step;
+    f.polar_rho2 = (float)(0.04 * c->radius * c->radius);
+    f.row_hi = std::nextafterf((float)c->dem_h, 0.0f);
+    f.col_hi = std::nextafterf((float)c->dem_w, 0.0f);
     set_grid(f.gd, c->dem_h, c->dem_w);
     f.dlat_scale = (float)((double)c->dem_h / (2.0 * kPiD));
     f.dlon_scale = (float)((double)c->dem_w / (4.0 * kPiD));

@@ -26,7 +26,8 @@ struct FrameC {
     int32_t sun_on;
     float sc[3], sun_cq, sun_rad;
     // D2 march (moon_renderer.py:586-588)
-    float step, eps, scene_eps;
+    float step, eps, scene_eps, inv_step;
+    float polar_rho2, row_hi, col_hi;   // segment fallback threshold (0.04 R^2); largest floats below h / w
     int32_t nbis, kmax;
     float dlat_scale, dlon_scale;
     GridC gd, gc;

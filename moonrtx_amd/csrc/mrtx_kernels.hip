@@ -181,17 +181,97 @@ __device__ __forceinline__ float dem_at(const FrameC& f, float rowf, float colf)
     return lerp2(d[a + t.ca], d[a + t.cb], d[b + t.ca], d[b + t.cb], t.fr, t.fc);
 }
 
-// D2/D3: is the point (moon frame) at or below the displaced surface?  r^2 <= (R * D(lat,lon))^2
-template <bool WIDE>
-__device__ __forceinline__ bool below_surface(const FrameC& f, float pa, float pb, float pc) {
-    const float rho2 = fmaf(pb, pb, pa * pa);
-    const float r2 = fmaf(pc, pc, rho2);
+// ---- D2/D3: the march.
+// Texel coordinates are smooth along a ray, while the exact (lat, lon) -> (row, col) costs ~65 VALU (sqrt,
+// reciprocal, two degree-15 polynomials, octant logic) and this kernel is VALU-issue bound.  Per SEG_N-step
+// segment the exact coordinates are evaluated at the segment's start, middle and end only; the steps in
+// between use the quadratic through those three (|error| <= ~1e-3 row / 7e-3 column texels for rho >= 0.2 R,
+// i.e. the float32 resolution of the coordinate itself).  Segments that touch the polar cap or straddle
+// the +/-180 seam evaluate every step exactly.  DEM evaluations, hit tests and counters are unchanged.
+constexpr int SEG_N = 16;
+struct Seg {
+    float sa, ra, r1, r2, ca, c1, c2;
+    bool exact;
+};
+
+__device__ __forceinline__ void exact_rowcol(const FrameC& f, float pa, float pb, float pc, float& rowf, float& colf,
+                                             float& rho2) {
+    rho2 = fmaf(pb, pb, pa * pa);
     float lat, lon;
     latlon(pa, pb, pc, rho2, lat, lon);
-    const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
-    const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
+    rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
+    colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
+}
+
+__device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                          int ka, float rowA, float colA, float q2A, Seg& sg, float& rowB,
+                                          float& colB, float& q2B) {
+    const float sm = (float)(ka + SEG_N / 2) * f.step, sb = (float)(ka + SEG_N) * f.step;
+    float rM, cM, q2M;
+    exact_rowcol(f, fmaf(sm, da, oa), fmaf(sm, db, ob), fmaf(sm, dc, oc), rM, cM, q2M);
+    exact_rowcol(f, fmaf(sb, da, oa), fmaf(sb, db, ob), fmaf(sb, dc, oc), rowB, colB, q2B);
+    const float hw = 0.5f * f.gd.wf;
+    const float qmin = fminf(q2A, fminf(q2M, q2B));
+    sg.exact = (fabsf(cM - colA) > hw) || (fabsf(colB - colA) > hw) || (qmin < f.polar_rho2);
+    sg.sa = (float)ka * f.step;
+    sg.ra = rowA; sg.ca = colA;
+    sg.r2 = (fmaf(-2.0f, rM, rowA) + rowB) * 0.0078125f;
+    sg.r1 = fmaf(-16.0f, sg.r2, (rowB - rowA) * 0.0625f);
+    sg.c2 = (fmaf(-2.0f, cM, colA) + colB) * 0.0078125f;
+    sg.c1 = fmaf(-16.0f, sg.c2, (colB - colA) * 0.0625f);
+}
+
+// is the point at or below the displaced surface?  r^2 <= (R * D(row, col))^2
+template <bool WIDE>
+__device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float sk, float pa, float pb, float pc,
+                                          float r2) {
+    float rowf, colf;
+    if (sg.exact) {
+        float q2;
+        exact_rowcol(f, pa, pb, pc, rowf, colf, q2);
+    } else {
+        const float u = (sk - sg.sa) * f.inv_step;
+        rowf = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra);
+        colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
+        rowf = __builtin_amdgcn_fmed3f(rowf, -1.0f, f.row_hi);
+        colf = __builtin_amdgcn_fmed3f(colf, -1.0f, f.col_hi);
+    }
     const float surf = f.Rf * dem_march<WIDE>(f, rowf, colf);
     return r2 <= surf * surf;
+}
+
+// Coarse march s_k = k*step, k = 1, 2, ...; returns true and k at the first sample at/below the surface.
+// PRIMARY: stop when s_k > smax (left the bounding sphere); shadow rays: stop when r^2 > R^2.
+// All lanes of a wave share k (the step counter lives in an SGPR); a lane drops out of the exec mask when it
+// hits or leaves, and the wave leaves the loop when no lane is still marching.
+template <bool WIDE, bool PRIMARY, bool STATS>
+__device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                      float smax, Seg& sg, int& k_hit, uint32_t* cnt) {
+    float rowA, colA, q2A;
+    exact_rowcol(f, oa, ob, oc, rowA, colA, q2A);
+    bool hit = false, go = true;
+    int ka = 0;
+    while (go) {
+        float rowB, colB, q2B;
+        seg_setup(f, oa, ob, oc, da, db, dc, ka, rowA, colA, q2A, sg, rowB, colB, q2B);
+        for (int j = 1; j <= SEG_N && go; j++) {
+            const int k = ka + j;
+            const float sk = (float)k * f.step;
+            const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
+            const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+            const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
+            bool bel = false;
+            if (in) {
+                bel = below_seg<WIDE>(f, sg, sk, pa, pb, pc, r2);
+                if (STATS) cnt[ST_HEIGHT]++;
+            }
+            hit = bel;
+            k_hit = k;
+            go = in & !bel;
+        }
+        ka += SEG_N; rowA = rowB; colA = colB; q2A = q2B;
+    }
+    return hit;
 }
 
 struct SampleOut {
@@ -244,28 +324,16 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         db = (float)((f.M[1][0] * Dx + f.M[1][1] * Dy) + f.M[1][2] * Dz);
         dc = (float)((f.M[2][0] * Dx + f.M[2][1] * Dy) + f.M[2][2] * Dz);
         const float smax = (float)(t1 - t0);
-        // coarse march: one exit test per trip (the wave leaves when no lane is still marching)
-        float hi = 0.0f;
+        Seg sg;
         int k = 0;
-        bool go = true;
-        while (go) {
-            k++;
-            const float sk = (float)k * f.step;
-            const bool in = (sk <= smax) & (k <= f.kmax);
-            bool bel = false;
-            if (in) {
-                bel = below_surface<WIDE>(f, fmaf(sk, da, pa), fmaf(sk, db, pb), fmaf(sk, dc, pc));
-                if (STATS) cnt[ST_HEIGHT]++;
-            }
-            hit = bel;
-            hi = sk;
-            go = in & !bel;
-        }
+        hit = march<WIDE, true, STATS>(f, pa, pb, pc, da, db, dc, smax, sg, k, cnt);
         if (hit) {
+            float hi = (float)k * f.step;
             lo = (float)(k - 1) * f.step;
             for (int i = 0; i < f.nbis; i++) {
                 const float mid = 0.5f * (lo + hi);
-                const bool bel = below_surface<WIDE>(f, fmaf(mid, da, pa), fmaf(mid, db, pb), fmaf(mid, dc, pc));
+                const float ma = fmaf(mid, da, pa), mb = fmaf(mid, db, pb), mc = fmaf(mid, dc, pc);
+                const bool bel = below_seg<WIDE>(f, sg, mid, ma, mb, mc, fmaf(mc, mc, fmaf(mb, mb, ma * ma)));
                 hi = bel ? mid : hi;
                 lo = bel ? lo : mid;
             }
@@ -389,26 +457,11 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     if (!(cosi > 0.0f)) return;
 
     if (STATS) cnt[ST_SHADOW]++;
-    bool occluded = false;
     {
-        int k = 0;
-        bool go = true;
-        while (go) {
-            k++;
-            const float sk = (float)k * f.step;
-            const float qa = fmaf(sk, wa, oa), qb = fmaf(sk, wb, ob), qc = fmaf(sk, wc, oc);
-            const float q2 = fmaf(qc, qc, fmaf(qb, qb, qa * qa));
-            const bool in = (q2 <= f.R2f) & (k <= f.kmax);
-            bool bel = false;
-            if (in) {
-                bel = below_surface<WIDE>(f, qa, qb, qc);
-                if (STATS) cnt[ST_HEIGHT]++;
-            }
-            occluded = bel;
-            go = in & !bel;
-        }
+        Seg ssg;
+        int kk = 0;
+        if (march<WIDE, false, STATS>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, kk, cnt)) return;
     }
-    if (occluded) return;
     const float wgt = (f.rad2 * omc) * cosi;
     o.c0 = al0 * wgt; o.c1 = al1 * wgt; o.c2 = al2 * wgt;
 }
@@ -422,8 +475,11 @@ __device__ __forceinline__ float tree_sum(float v) {
 
 // One wave = 64 (pixel, sample) pairs: P = 64/S pixels (PW x PH block) x S samples in adjacent lanes.
 // One 256-thread workgroup = one 16x16-pixel sub-tile of a sharding tile.
+#ifndef MRTX_MIN_WAVES
+#define MRTX_MIN_WAVES 5   // 94 VGPRs, 5 waves/SIMD, no spill: best of {4,5,6,8} measured (profiles/)
+#endif
 template <int S, bool STATS, bool WIDE>
-__global__ void __launch_bounds__(256) render_kernel(const FrameC f) {
+__global__ void __launch_bounds__(256, MRTX_MIN_WAVES) render_kernel(const FrameC f) {
     constexpr int P = 64 / S;
     constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;
     constexpr int PH = P / PW;

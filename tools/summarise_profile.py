@@ -17,7 +17,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         continue
     for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if "render_kernel<64, false>" in r["Kernel_Name"] or "render_kernel<64,false>" in r["Kernel_Name"]:
+            if "render_kernel<64, false" in r["Kernel_Name"]:
                 pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
                 meta = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
