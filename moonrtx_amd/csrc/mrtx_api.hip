@@ -40,7 +40,7 @@ struct mrtx_ctx {
     float* accum = nullptr;
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
-    float* dem = nullptr; int dem_h = 0, dem_w = 0;   // padded (h+2) x (w+2) copy, always owned
+    float* dem = nullptr; int dem_h = 0, dem_w = 0;   // padded (h+4) x (w+4) copy, always owned
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
     unsigned long long* stats_dev = nullptr;
@@ -150,7 +150,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     f.scene_eps = c->prm.scene_epsilon;
     f.nbis = 0;
     for (double wdt = (double)f.step; wdt > (double)f.eps && f.nbis < 24; wdt *= 0.5) f.nbis++;
-    f.kmax = (int)(2.0 * c->radius / (double)f.step) + 8;
+    f.kmax = (((int)(2.0 * c->radius / (double)f.step) + 8) + 15) & ~15;   // multiple of the 16-step segment
     f.inv_step = 1.0f / f.step;
     f.polar_rho2 = (float)(0.04 * c->radius * c->radius);
     f.row_hi = std::nextafterf((float)c->dem_h, 0.0f);
@@ -169,9 +169,9 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     f.key0 = mix32h(c->prm.seed ^ 0x9E3779B9u);
     for (int i = 0; i < 3; i++) f.const_albedo[i] = c->prm.const_albedo[i];
     f.dem = c->dem; f.color = c->color; f.bg = c->bg;
-    f.dem_pitch = c->dem_w + 2;
-    f.dem_maxidx = (uint32_t)((uint64_t)c->dem_h * (uint64_t)(c->dem_w + 2) + (uint64_t)c->dem_w);
-    f.dem_wide = ((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 2) * 4ull > 0xFFFFFFFFull) ? 1 : 0;
+    f.dem_pitch = c->dem_w + 4;
+    f.dem_maxidx = (uint32_t)((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 4) + (uint64_t)(c->dem_w + 2));
+    f.dem_wide = ((uint64_t)(c->dem_h + 4) * (uint64_t)(c->dem_w + 4) * 4ull > 0xFFFFFFFFull) ? 1 : 0;
     f.tile_w = c->cfg.tile_w; f.tile_h = c->cfg.tile_h;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y;
     f.rank = c->cfg.rank; f.world = c->cfg.world; f.n_local_tiles = c->n_local;
@@ -263,7 +263,7 @@ const char* mrtx_last_error(mrtx_ctx* c) { return c ? c->err.c_str() : "null con
 static int ingest_dem(mrtx_ctx* c, const float* dev_src, int32_t h, int32_t w) {
     if (c->dem) { HIPCHK(c, hipFree(c->dem)); }
     c->dem = nullptr; c->dem_h = c->dem_w = 0;
-    const size_t bytes = (size_t)(h + 2) * (size_t)(w + 2) * sizeof(float);
+    const size_t bytes = (size_t)(h + 4) * (size_t)(w + 4) * sizeof(float);
     HIPCHK(c, hipMalloc((void**)&c->dem, bytes));
     HIPCHK(c, mrtx_launch_pad_dem(dev_src, c->dem, h, w, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -476,7 +476,7 @@ int mrtx_device_ptr(mrtx_ctx* c, int32_t which, void** out, uint64_t* bytes) {
     switch (which) {
         case MRTX_BUF_ACCUM: *out = c->accum; if (bytes) *bytes = fb; break;
         case MRTX_BUF_HITS: *out = c->hits; if (bytes) *bytes = fb; break;
-        case MRTX_BUF_DEM: *out = c->dem; if (bytes) *bytes = c->dem ? (uint64_t)(c->dem_h + 2) * (c->dem_w + 2) * 4 : 0; break;
+        case MRTX_BUF_DEM: *out = c->dem; if (bytes) *bytes = c->dem ? (uint64_t)(c->dem_h + 4) * (c->dem_w + 4) * 4 : 0; break;
         case MRTX_BUF_COLOR: *out = c->color; if (bytes) *bytes = (uint64_t)c->color_h * c->color_w * 4; break;
         default: return fail(c, MRTX_E_INVALID, "unknown buffer id %d", which);
     }

@@ -35,9 +35,9 @@ struct FrameC {
     float bg_row_scale, bg_row_off, bg_col_scale, bg_col_off;
     uint32_t key0;
     float const_albedo[3];
-    const float* dem;       // PADDED (h+2) x (w+2): element [0] is (row -1, col -1); see dem_march()
-    int32_t dem_pitch, dem_wide;   // pitch = w+2 floats; wide = byte offsets need 64 bits (> 4 GiB)
-    uint32_t dem_maxidx;           // h*pitch + w: last padded index a 2x2 tap may start at
+    const float* dem;       // PADDED (h+4) x (w+4): element [0] is (row -2, col -2); see dem_march()
+    int32_t dem_pitch, dem_wide;   // pitch = w+4 floats; wide = byte offsets need 64 bits (> 4 GiB)
+    uint32_t dem_maxidx;           // (h+2)*pitch + (w+2): last padded index a 2x2 tap may start at
     const uint8_t* color;   // RGBA8 or null
     const uint8_t* bg;      // RGBA8 or null
     // image-tile sharding (new) + accumulation state

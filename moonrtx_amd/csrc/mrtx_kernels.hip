@@ -28,6 +28,7 @@ namespace mrtx {
 
 __device__ constexpr float kPi = 3.14159274101257324f;
 __device__ constexpr float kHalfPi = 1.57079637050628662f;
+__device__ constexpr float kInv255 = 0.003921568859368563f;
 
 enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_N };
 
@@ -121,19 +122,19 @@ __device__ __forceinline__ float lerp2(float e00, float e01, float e10, float e1
 // Bilinear taps, floor() form of renderer_navigation.py:581-588: r0 = floor(row), c0 = floor(col); rows r0 and
 // r0+1 clamp to [0,h-1], columns c0 and c0+1 wrap into [0,w).
 //
-// The DEM lives in HBM PADDED by one texel on every side (row -1 = row 0, row h = row h-1, column -1 =
-// column w-1, column w = column 0; pitch = w+2), so on the march path -- where (row, col) come from a
-// (lat, lon) and floor() lands in [-1,h-1] x [-1,w-1] -- a bilinear evaluation is two unconditional 8-byte
-// loads, no clamp, no wrap, no seam branch.
+// The DEM lives in HBM PADDED by two texels on every side (rows -2,-1 = row 0, rows h,h+1 = row h-1, columns
+// -2,-1 = columns w-2,w-1, columns w,w+1 = columns 0,1; pitch = w+4), so a bilinear evaluation -- on the march
+// path, where floor() lands in [-1,h-1] x [-1,w-1], and one texel either side of it for the normal -- is two
+// unconditional 8-byte loads: no clamp, no wrap, no seam branch.
 struct __attribute__((packed, aligned(4))) Pair { float x, y; };
 
 template <bool WIDE>
 __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float colf) {
     const float rfl = floorf(rowf), cfl = floorf(colf);
     const float fr = rowf - rfl, fc = colf - cfl;
-    // padded index of (r0, c0) = (r0+1)*pitch + (c0+1); both factors < 2^24 -> one v_mad_u32_u24.  A single
+    // padded index of (r0, c0) = (r0+2)*pitch + (c0+2); both factors < 2^24 -> one v_mad_u32_u24.  A single
     // unsigned min keeps any garbage (NaN position) inside the array; it never bites for a valid (lat, lon).
-    const uint32_t r0p = (uint32_t)((int)rfl + 1), c0p = (uint32_t)((int)cfl + 1);
+    const uint32_t r0p = (uint32_t)((int)rfl + 2), c0p = (uint32_t)((int)cfl + 2);
     const uint32_t idx = min(__umul24(r0p, (uint32_t)f.dem_pitch) + c0p, f.dem_maxidx);
     const char* base = reinterpret_cast<const char*>(f.dem);
     Pair t, u;
@@ -174,13 +175,6 @@ __device__ __forceinline__ Tap grid_tap(const GridC& g, float rowf, float colf) 
     t.fr = rowf - rfl; t.fc = colf - cfl;
     return t;
 }
-__device__ __forceinline__ float dem_at(const FrameC& f, float rowf, float colf) {
-    const Tap t = grid_tap(f.gd, rowf, colf);
-    const float* __restrict__ d = f.dem;
-    const int64_t a = (int64_t)(t.ra + 1) * f.dem_pitch + 1, b = (int64_t)(t.rb + 1) * f.dem_pitch + 1;
-    return lerp2(d[a + t.ca], d[a + t.cb], d[b + t.ca], d[b + t.cb], t.fr, t.fc);
-}
-
 // ---- D2/D3: the march.
 // Texel coordinates are smooth along a ray, while the exact (lat, lon) -> (row, col) costs ~65 VALU (sqrt,
 // reciprocal, two degree-15 polynomials, octant logic) and this kernel is VALU-issue bound.  Per SEG_N-step
@@ -222,31 +216,52 @@ __device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, f
 }
 
 // is the point at or below the displaced surface?  r^2 <= (R * D(row, col))^2
-template <bool WIDE>
+// EXACTABLE = false: the caller knows (by ballot) that no lane of the wave is in an exact-fallback segment.
+// The quadratic needs no clamp: a non-seam, non-polar segment keeps (row, col) >= 0.5 texel inside
+// [-1, h) x [-1, w), and dem_march()'s unsigned index clamp keeps even a NaN inside the allocation.
+template <bool WIDE, bool EXACTABLE>
 __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float sk, float pa, float pb, float pc,
                                           float r2) {
-    float rowf, colf;
-    if (sg.exact) {
+    const float u = (sk - sg.sa) * f.inv_step;
+    float rowf = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra);
+    float colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
+    if (EXACTABLE && sg.exact) {
         float q2;
         exact_rowcol(f, pa, pb, pc, rowf, colf, q2);
-    } else {
-        const float u = (sk - sg.sa) * f.inv_step;
-        rowf = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra);
-        colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
-        rowf = __builtin_amdgcn_fmed3f(rowf, -1.0f, f.row_hi);
-        colf = __builtin_amdgcn_fmed3f(colf, -1.0f, f.col_hi);
     }
     const float surf = f.Rf * dem_march<WIDE>(f, rowf, colf);
     return r2 <= surf * surf;
 }
 
-// Coarse march s_k = k*step, k = 1, 2, ...; returns true and k at the first sample at/below the surface.
+// The 16 steps of one segment.  Branch-free body: the DEM is sampled even on the step that turns out to lie
+// outside (its result is discarded; at most one wasted sample per ray), so the only control flow is the
+// loop-back on the ballot of lanes still marching.
+template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE>
+__device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                          float smax, const Seg& sg, int ka, bool& go, bool& hit, float& sk_out,
+                                          uint32_t* cnt) {
+    int j = 0;
+    do {
+        j++;
+        const float sk = (float)(ka + j) * f.step;
+        const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
+        const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+        const bool in = PRIMARY ? (sk <= smax) : (r2 <= f.R2f);
+        const bool bel = below_seg<WIDE, EXACTABLE>(f, sg, sk, pa, pb, pc, r2);
+        if (STATS) cnt[ST_HEIGHT] += in ? 1u : 0u;
+        hit = in & bel;
+        go = in & !bel;
+        sk_out = sk;
+    } while (go && j < SEG_N);
+}
+
+// Coarse march s_k = k*step, k = 1, 2, ...; returns true and s_k at the first sample at/below the surface.
 // PRIMARY: stop when s_k > smax (left the bounding sphere); shadow rays: stop when r^2 > R^2.
 // All lanes of a wave share k (the step counter lives in an SGPR); a lane drops out of the exec mask when it
-// hits or leaves, and the wave leaves the loop when no lane is still marching.
+// hits or leaves, and the wave leaves the loop when no lane is still marching.  f.kmax is a multiple of SEG_N.
 template <bool WIDE, bool PRIMARY, bool STATS>
 __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
-                                      float smax, Seg& sg, int& k_hit, uint32_t* cnt) {
+                                      float smax, Seg& sg, float& sk_hit, uint32_t* cnt) {
     float rowA, colA, q2A;
     exact_rowcol(f, oa, ob, oc, rowA, colA, q2A);
     bool hit = false, go = true;
@@ -254,22 +269,12 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
     while (go) {
         float rowB, colB, q2B;
         seg_setup(f, oa, ob, oc, da, db, dc, ka, rowA, colA, q2A, sg, rowB, colB, q2B);
-        for (int j = 1; j <= SEG_N && go; j++) {
-            const int k = ka + j;
-            const float sk = (float)k * f.step;
-            const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
-            const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
-            const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
-            bool bel = false;
-            if (in) {
-                bel = below_seg<WIDE>(f, sg, sk, pa, pb, pc, r2);
-                if (STATS) cnt[ST_HEIGHT]++;
-            }
-            hit = bel;
-            k_hit = k;
-            go = in & !bel;
-        }
+        if (__ballot(sg.exact) != 0ull)
+            step_loop<WIDE, PRIMARY, STATS, true>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+        else
+            step_loop<WIDE, PRIMARY, STATS, false>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
         ka += SEG_N; rowA = rowB; colA = colB; q2A = q2B;
+        go = go & (ka < f.kmax);
     }
     return hit;
 }
@@ -297,8 +302,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     float dx = fmaf(sy, f.Vy[0], fmaf(sx, f.Ux[0], f.Wd[0]));
     float dy = fmaf(sy, f.Vy[1], fmaf(sx, f.Ux[1], f.Wd[1]));
     float dz = fmaf(sy, f.Vy[2], fmaf(sx, f.Ux[2], f.Wd[2]));
-    const float len = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-    dx = dx / len; dy = dy / len; dz = dz / len;
+    const float inv_len = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    dx = dx * inv_len; dy = dy * inv_len; dz = dz * inv_len;
 
     // float64 entry into the bounding sphere: the eye sits ~30 radii away, float32 would cost metres
     const double Dx = (double)dx, Dy = (double)dy, Dz = (double)dz;
@@ -308,9 +313,12 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     bool on_sphere = false;
     double t0 = 0.0, t1 = 0.0;
     if (disc > 0.0) {
-        const double sq = sqrt(disc);
-        t0 = (-b - sq) / a;
-        t1 = (-b + sq) / a;
+        // products/sums in float64; the root and the 1/a scale in float32 (f64 sqrt and division are ~35
+        // instructions each): their rounding moves the entry point along the ray only
+        const double sq = (double)sqrtf((float)disc);
+        const double inva = (double)(1.0f / (float)a);
+        t0 = (-b - sq) * inva;
+        t1 = (-b + sq) * inva;
         if (t1 > 0.0) { on_sphere = true; if (t0 < 0.0) t0 = 0.0; }
     }
     bool hit = false;
@@ -325,15 +333,16 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         dc = (float)((f.M[2][0] * Dx + f.M[2][1] * Dy) + f.M[2][2] * Dz);
         const float smax = (float)(t1 - t0);
         Seg sg;
-        int k = 0;
-        hit = march<WIDE, true, STATS>(f, pa, pb, pc, da, db, dc, smax, sg, k, cnt);
+        float hi = 0.0f;
+        hit = march<WIDE, true, STATS>(f, pa, pb, pc, da, db, dc, smax, sg, hi, cnt);
         if (hit) {
-            float hi = (float)k * f.step;
+            // hi = (float)k * step of the first sample below; k recovered exactly (|k*step/step - k| << 0.5)
+            const int k = (int)rintf(hi * f.inv_step);
             lo = (float)(k - 1) * f.step;
             for (int i = 0; i < f.nbis; i++) {
                 const float mid = 0.5f * (lo + hi);
                 const float ma = fmaf(mid, da, pa), mb = fmaf(mid, db, pb), mc = fmaf(mid, dc, pc);
-                const bool bel = below_seg<WIDE>(f, sg, mid, ma, mb, mc, fmaf(mc, mc, fmaf(mb, mb, ma * ma)));
+                const bool bel = below_seg<WIDE, true>(f, sg, mid, ma, mb, mc, fmaf(mc, mc, fmaf(mb, mb, ma * ma)));
                 hi = bel ? mid : hi;
                 lo = bel ? lo : mid;
             }
@@ -366,9 +375,9 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
             if (c >= f.bg_w) c -= f.bg_w;
             if (c < 0) c = 0;
             const uint32_t px = reinterpret_cast<const uint32_t*>(f.bg)[(int64_t)r * f.bg_w + c];
-            o.c0 = (float)(px & 255u) / 255.0f;
-            o.c1 = (float)((px >> 8) & 255u) / 255.0f;
-            o.c2 = (float)((px >> 16) & 255u) / 255.0f;
+            o.c0 = (float)(px & 255u) * kInv255;
+            o.c1 = (float)((px >> 8) & 255u) * kInv255;
+            o.c2 = (float)((px >> 16) & 255u) * kInv255;
             if (STATS) cnt[ST_BG]++;
         }
         return;
@@ -385,10 +394,11 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     latlon(ha, hb, hc, rho2, lat, lon);
     const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
     const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
-    const float dn = dem_at(f, rowf - 1.0f, colf);
-    const float ds = dem_at(f, rowf + 1.0f, colf);
-    const float de = dem_at(f, rowf, colf + 1.0f);
-    const float dw = dem_at(f, rowf, colf - 1.0f);
+    // the two-texel border makes the +-1 texel taps plain two-load evaluations as well
+    const float dn = dem_march<WIDE>(f, rowf - 1.0f, colf);
+    const float ds = dem_march<WIDE>(f, rowf + 1.0f, colf);
+    const float de = dem_march<WIDE>(f, rowf, colf + 1.0f);
+    const float dw = dem_march<WIDE>(f, rowf, colf - 1.0f);
     if (STATS) cnt[ST_HEIGHT] += 4;
     const float dlat = (dn - ds) * f.dlat_scale;
     const float dlon = (de - dw) * f.dlon_scale;
@@ -401,8 +411,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
     float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
     float nc = fmaf(-glat, cphi, hc * inv_r);
-    const float nl = sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
-    na = na / nl; nb = nb / nl; nc = nc / nl;
+    const float inv_nl = 1.0f / sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
+    na = na * inv_nl; nb = nb * inv_nl; nc = nc * inv_nl;
 
     float al0, al1, al2;
     if (f.color) {  // D4: bilinear RGBA8
@@ -412,11 +422,11 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         const uint32_t* tex = reinterpret_cast<const uint32_t*>(f.color);
         const int64_t ra = (int64_t)t.ra * f.gc.w, rb = (int64_t)t.rb * f.gc.w;
         const uint32_t p00 = tex[ra + t.ca], p01 = tex[ra + t.cb], p10 = tex[rb + t.ca], p11 = tex[rb + t.cb];
-        al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), t.fr, t.fc) / 255.0f;
+        al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), t.fr, t.fc) * kInv255;
         al1 = lerp2((float)((p00 >> 8) & 255u), (float)((p01 >> 8) & 255u), (float)((p10 >> 8) & 255u),
-                    (float)((p11 >> 8) & 255u), t.fr, t.fc) / 255.0f;
+                    (float)((p11 >> 8) & 255u), t.fr, t.fc) * kInv255;
         al2 = lerp2((float)((p00 >> 16) & 255u), (float)((p01 >> 16) & 255u), (float)((p10 >> 16) & 255u),
-                    (float)((p11 >> 16) & 255u), t.fr, t.fc) / 255.0f;
+                    (float)((p11 >> 16) & 255u), t.fr, t.fc) * kInv255;
         if (STATS) cnt[ST_COLOUR]++;
     } else {
         al0 = f.const_albedo[0]; al1 = f.const_albedo[1]; al2 = f.const_albedo[2];
@@ -433,9 +443,9 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     const float oa = fmaf(eps, na, ha), ob = fmaf(eps, nb, hb), oc = fmaf(eps, nc, hc);
     const float ta = f.Lb[0] - oa, tb = f.Lb[1] - ob, tc = f.Lb[2] - oc;
     const float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
-    const float dist = sqrtf(d2);
-    const float la = ta / dist, lb = tb / dist, lc = tc / dist;
-    float sin2 = f.rL2 / d2;
+    const float inv_dist = 1.0f / sqrtf(d2);
+    const float la = ta * inv_dist, lb = tb * inv_dist, lc = tc * inv_dist;
+    float sin2 = f.rL2 * (inv_dist * inv_dist);
     if (sin2 > 1.0f) sin2 = 1.0f;
     const float cosmax = sqrtf(1.0f - sin2);
     const float omc = sin2 / (1.0f + cosmax);
@@ -459,8 +469,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     if (STATS) cnt[ST_SHADOW]++;
     {
         Seg ssg;
-        int kk = 0;
-        if (march<WIDE, false, STATS>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, kk, cnt)) return;
+        float sk_occ;
+        if (march<WIDE, false, STATS>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return;
     }
     const float wgt = (f.rad2 * omc) * cosi;
     o.c0 = al0 * wgt; o.c1 = al1 * wgt; o.c2 = al2 * wgt;
@@ -758,14 +768,14 @@ __global__ void probe_latlon_kernel(const float* a, const float* b, const float*
     if (i < n) latlon(a[i], b[i], c[i], fmaf(b[i], b[i], a[i] * a[i]), lat[i], lon[i]);
 }
 
-// DEM (h, w) row-major -> padded (h+2, w+2): row -1 = row 0, row h = row h-1, col -1 = col w-1, col w = col 0
+// DEM (h, w) row-major -> padded (h+4, w+4): rows clamp, columns wrap (see dem_march)
 __global__ void pad_dem_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w) {
-    const int pitch = w + 2;
-    const int64_t n = (int64_t)(h + 2) * pitch;
+    const int pitch = w + 4;
+    const int64_t n = (int64_t)(h + 4) * pitch;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int r = (int)(i / pitch) - 1, c = (int)(i % pitch) - 1;
+        int r = (int)(i / pitch) - 2, c = (int)(i % pitch) - 2;
         r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
-        c = c < 0 ? w - 1 : (c > w - 1 ? 0 : c);
+        c = c < 0 ? c + w : (c > w - 1 ? c - w : c);
         dst[i] = src[(int64_t)r * w + c];
     }
 }
@@ -850,7 +860,7 @@ hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float*
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st) {
-    hipLaunchKernelGGL(mrtx::pad_dem_kernel, dim3(grid_for((int64_t)(h + 2) * (w + 2))), dim3(256), 0, st, src, dst, h, w);
+    hipLaunchKernelGGL(mrtx::pad_dem_kernel, dim3(grid_for((int64_t)(h + 4) * (w + 4))), dim3(256), 0, st, src, dst, h, w);
     return hipGetLastError();
 }
 }

@@ -61,6 +61,7 @@ enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_N };
 #define PI_D 3.14159265358979323846
 static const float PI_F = 3.14159274101257324f;
 static const float HALF_PI_F = 1.57079637050628662f;
+static const float INV255 = 0.003921568859368563f;   /* (float)(1/255) */
 /* atan(q) ~= q * P(q^2) on [0,1], |err| <= 1.3e-7 */
 static const float AT0 = 0.9999993443489075f, AT1 = -0.33329859375953674f, AT2 = 0.19946560263633728f,
                    AT3 = -0.1390860229730606f, AT4 = 0.0964212492108345f, AT5 = -0.05591127648949623f,
@@ -275,7 +276,7 @@ static void frame_init(Frame* f, const OrcScene* s) {
     f->eps = s->marching_step_eps;
     f->nbis = 0;
     { double wdt = (double)f->step; while (wdt > (double)f->eps && f->nbis < 24) { wdt *= 0.5; f->nbis++; } }
-    f->kmax = (int)(2.0 * s->radius / (double)f->step) + 8;
+    f->kmax = (((int)(2.0 * s->radius / (double)f->step) + 8) + 15) & ~15;   /* multiple of SEG_N */
     f->inv_step = 1.0f / f->step;
     f->polar_rho2 = (float)(0.04 * s->radius * s->radius);
     f->row_hi = nextafterf((float)s->dem_h, 0.0f);
@@ -317,6 +318,7 @@ void orc_frame_floats(const OrcScene* s, float* out) {
  * coordinate itself).  Segments that touch the polar cap (rho < 0.2 R) or straddle the +/-180 seam evaluate
  * every step exactly. */
 #define SEG_N 16
+static uint64_t orc_quad_out_of_range = 0;   /* must stay 0; tests read it through orc_debug_counter() */
 typedef struct Seg { float sa, ra, r1, r2, ca, c1, c2; int exact; } Seg;
 typedef struct Ray { float oa, ob, oc, da, db, dc; } Ray;
 
@@ -356,8 +358,11 @@ static inline int below_seg(const OrcScene* s, const Frame* f, const Seg* sg, fl
         float u = (sk - sg->sa) * f->inv_step;
         rowf = fmaf(u, fmaf(u, sg->r2, sg->r1), sg->ra);
         colf = fmaf(u, fmaf(u, sg->c2, sg->c1), sg->ca);
-        rowf = rowf < -1.0f ? -1.0f : (rowf > f->row_hi ? f->row_hi : rowf);
-        colf = colf < -1.0f ? -1.0f : (colf > f->col_hi ? f->col_hi : colf);
+        /* a non-seam, non-polar segment keeps the quadratic well inside [-1, h) x [-1, w): counted, never clamped */
+        if (!(rowf >= -1.0f && rowf <= f->row_hi && colf >= -1.0f && colf <= f->col_hi)) {
+#pragma omp atomic
+            orc_quad_out_of_range++;
+        }
     }
     float d = dem_at(s->dem, &f->gd, rowf, colf);
     st[ST_HEIGHT]++;
@@ -408,8 +413,8 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
     float dx = fmaf(sy, f->Vy[0], fmaf(sx, f->Ux[0], f->Wd[0]));
     float dy = fmaf(sy, f->Vy[1], fmaf(sx, f->Ux[1], f->Wd[1]));
     float dz = fmaf(sy, f->Vy[2], fmaf(sx, f->Ux[2], f->Wd[2]));
-    float len = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-    dx = dx / len; dy = dy / len; dz = dz / len;
+    float inv_len = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    dx = dx * inv_len; dy = dy * inv_len; dz = dz * inv_len;
 
     /* float64 entry into the bounding sphere */
     double Dx = (double)dx, Dy = (double)dy, Dz = (double)dz;
@@ -419,9 +424,12 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
     int on_sphere = 0;
     double t0 = 0.0, t1 = 0.0;
     if (disc > 0.0) {
-        double sq = sqrt(disc);
-        t0 = (-b - sq) / a;
-        t1 = (-b + sq) / a;
+        /* products and sums in float64 (the eye is 30 radii away); the root and the 1/a scale in float32:
+         * their rounding moves the entry point ALONG the ray only (<= 2e-5 units), which the march absorbs */
+        double sq = (double)sqrtf((float)disc);
+        double inva = (double)(1.0f / (float)a);
+        t0 = (-b - sq) * inva;
+        t1 = (-b + sq) * inva;
         if (t1 > 0.0) { on_sphere = 1; if (t0 < 0.0) t0 = 0.0; }
     }
     int hit = 0;
@@ -477,9 +485,9 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
             if (c >= s->bg_w) c -= s->bg_w;
             if (c < 0) c = 0;
             const uint8_t* px = s->bg + 4 * ((int64_t)r * s->bg_w + c);
-            o->c[0] = (float)px[0] / 255.0f;
-            o->c[1] = (float)px[1] / 255.0f;
-            o->c[2] = (float)px[2] / 255.0f;
+            o->c[0] = (float)px[0] * INV255;
+            o->c[1] = (float)px[1] * INV255;
+            o->c[2] = (float)px[2] * INV255;
             st[ST_BG]++;
         }
         return;
@@ -512,8 +520,8 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
     float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
     float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
     float nc = fmaf(-glat, cphi, hc * inv_r);
-    float nl = sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
-    na = na / nl; nb = nb / nl; nc = nc / nl;
+    float inv_nl = 1.0f / sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
+    na = na * inv_nl; nb = nb * inv_nl; nc = nc * inv_nl;
 
     float alb[3];
     if (s->color) {
@@ -523,7 +531,7 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
         for (ch = 0; ch < 3; ch++) {
             float v = lerp2((float)s->color[4 * t.i00 + ch], (float)s->color[4 * t.i01 + ch],
                             (float)s->color[4 * t.i10 + ch], (float)s->color[4 * t.i11 + ch], t.fr, t.fc);
-            alb[ch] = v / 255.0f;
+            alb[ch] = v * INV255;
         }
         st[ST_COLOUR]++;
     } else {
@@ -541,9 +549,9 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
     float oa = fmaf(eps, na, ha), ob = fmaf(eps, nb, hb), occ = fmaf(eps, nc, hc);
     float ta = f->Lb[0] - oa, tb = f->Lb[1] - ob, tc = f->Lb[2] - occ;
     float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
-    float dist = sqrtf(d2);
-    float la = ta / dist, lb = tb / dist, lc = tc / dist;
-    float sin2 = f->rL2 / d2;
+    float inv_dist = 1.0f / sqrtf(d2);
+    float la = ta * inv_dist, lb = tb * inv_dist, lc = tc * inv_dist;
+    float sin2 = f->rL2 * (inv_dist * inv_dist);
     if (sin2 > 1.0f) sin2 = 1.0f;
     float cosmax = sqrtf(1.0f - sin2);
     float omc = sin2 / (1.0f + cosmax);
@@ -671,6 +679,7 @@ float orc_dem_from_ldem(const int16_t* src, int32_t h, int32_t w, int32_t d, flo
 }
 
 int orc_sizeof_scene(void) { return (int)sizeof(OrcScene); }
+uint64_t orc_debug_counter(void) { return orc_quad_out_of_range; }
 
 /* number of OpenMP threads orc_render uses from now on; returns the count in effect */
 int orc_set_threads(int n) {

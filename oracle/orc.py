@@ -76,11 +76,17 @@ def lib():
         L.orc_dem_from_ldem.restype = C.c_float
         L.orc_dem_from_ldem.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.orc_sizeof_scene.restype = C.c_int
+        L.orc_debug_counter.restype = C.c_uint64
         L.orc_set_threads.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
         assert L.orc_sizeof_scene() == C.sizeof(OrcScene), "OrcScene layout mismatch"
         _lib = L
     return _lib
+
+
+def quad_out_of_range():
+    """Number of quadratic-segment taps that left [-1, h) x [-1, w) since load; the spec requires 0."""
+    return int(lib().orc_debug_counter())
 
 
 def set_threads(n):
