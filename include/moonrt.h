@@ -65,6 +65,7 @@ typedef struct MrtxParams {
 } MrtxParams;
 
 #define MRTX_F_COUNT_STATS 1u  /* maintain the deterministic sample counters of MrtxStats */
+#define MRTX_F_FORCE_WIDE  2u  /* test hook: use the 64-bit DEM addressing path (normally only for DEMs > 4 GiB) */
 
 typedef struct MrtxStats {
     uint64_t primary_rays;        /* camera samples (pixel x spp), the headline "ray"      */

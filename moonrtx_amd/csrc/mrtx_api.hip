@@ -390,6 +390,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     f.first_block = c->blocks_done;
     f.n_blocks = (uint32_t)n_blocks;
     const bool stats = (c->prm.flags & MRTX_F_COUNT_STATS) != 0;
+    if (c->prm.flags & MRTX_F_FORCE_WIDE) f.dem_wide = 1;
     if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->stream));

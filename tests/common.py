@@ -8,13 +8,14 @@ STAT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "c
              "background_fetches")
 
 
-def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, tile=(32, 32)):
+def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, tile=(32, 32), flags=1):
     rt = MoonRT(scene.width, scene.height, rank=rank, world=world, tile=tile)
     try:
         rt.upload_dem(dem)
         rt.upload_color(color)
         rt.upload_background(bg)
         rt.apply_scene(scene)
+        rt.set_params(flags=flags)
         stats = {k: 0 for k in STAT_KEYS}
         for nb in blocks:
             st = rt.render(nb)

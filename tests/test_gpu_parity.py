@@ -92,6 +92,27 @@ def test_ragged_dem_shapes(native_lib):
     check(named_scene("S2", 32, 32, spp_per_launch=4), tiny)
 
 
+def test_wide_addressing_path_matches(native_lib, dem_small):
+    """DEMs above 4 GiB (downscale 1: 17 GB) take 64-bit byte offsets; force that path on a small DEM."""
+    from moonrtx_amd import _lib
+    s = named_scene("S1", 80, 64, spp_per_launch=16)
+    col = synth_np.colour_map(90, 180)
+    lin_w, hits_w, st_w, _ = render_hip(s, dem_small, col, flags=_lib.F_COUNT_STATS | _lib.F_FORCE_WIDE)
+    lin_o, hits_o, st_o = render_oracle(s, dem_small, col)
+    assert_bit_equal(lin_w, lin_o, "wide path radiance")
+    assert_bit_equal(hits_w, hits_o, "wide path hits")
+    assert {k: st_w[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
+
+
+def test_polar_and_seam_views_use_exact_segments(native_lib, dem_small):
+    """Cameras over the poles and over the +/-180 seam: the segments there fall back to exact evaluation."""
+    from oracle import orc
+    for lib in ((0.0, 89.0), (0.0, -88.0), (179.5, 5.0), (-179.8, -40.0)):
+        s = named_scene("S2", 64, 64, spp_per_launch=4, libration=lib)
+        check(s, dem_small)
+    assert orc.quad_out_of_range() == 0
+
+
 def test_sharded_ranks_reassemble_bit_exact(native_lib, dem_small):
     """world=2 and world=3 on one GPU: each rank renders its tiles, rank 0 unpacks the peers' shards."""
     from moonrtx_amd.renderer import MoonRT, DeviceBuffer
