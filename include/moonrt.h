@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRTX_ABI_VERSION 1
+#define MRTX_ABI_VERSION 2
 
 enum {
     MRTX_OK = 0,
@@ -65,15 +65,20 @@ typedef struct MrtxParams {
 } MrtxParams;
 
 #define MRTX_F_COUNT_STATS 1u  /* maintain the deterministic sample counters of MrtxStats */
+#define MRTX_F_NO_SKIP     4u  /* evaluate every march step (disable the result-preserving max-mip skip) */
 #define MRTX_F_FORCE_WIDE  2u  /* test hook: use the 64-bit DEM addressing path (normally only for DEMs > 4 GiB) */
 
 typedef struct MrtxStats {
     uint64_t primary_rays;        /* camera samples (pixel x spp), the headline "ray"      */
     uint64_t primary_hits;        /* camera samples that hit the Moon                      */
     uint64_t shadow_rays;         /* light-sample rays marched                             */
-    uint64_t height_samples;      /* DEM bilinear evaluations (16 B each), all segments    */
+    uint64_t height_samples;      /* DEM bilinear evaluations the march DEFINES (16 B each): every step of every
+                                     segment until hit / exit, bisection, normal taps -- equals the oracle's count */
     uint64_t colour_fetches;      /* colour bilinear fetches (16 B each)                   */
     uint64_t background_fetches;  /* environment texel fetches (4 B each)                  */
+    uint64_t dem_fetches;         /* DEM bilinear evaluations actually PERFORMED (steps the max-mip bound proves to
+                                     be above the terrain are skipped; results are unchanged)                  */
+    uint64_t mip_fetches;         /* max-mip texels read for those bounds (4 B each)                           */
     double kernel_ms;             /* HIP-event time of the render kernel(s) of this call   */
     uint32_t launches;
     uint32_t reserved;

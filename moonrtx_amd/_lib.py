@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOONRT_LIB") or os.path.join(_HERE, "libmoonrt.so")   # MOONRT_LIB: A/B builds only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MrtxConfig(C.Structure):
@@ -28,12 +28,14 @@ class MrtxParams(C.Structure):
 class MrtxStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("primary_hits", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("height_samples", C.c_uint64), ("colour_fetches", C.c_uint64),
-                ("background_fetches", C.c_uint64), ("kernel_ms", C.c_double),
+                ("background_fetches", C.c_uint64), ("dem_fetches", C.c_uint64), ("mip_fetches", C.c_uint64),
+                ("kernel_ms", C.c_double),
                 ("launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 F_COUNT_STATS = 1
 F_FORCE_WIDE = 2
+F_NO_SKIP = 4
 BUF_ACCUM, BUF_HITS, BUF_DEM, BUF_COLOR = 0, 1, 2, 3
 
 _D3 = C.POINTER(C.c_double)

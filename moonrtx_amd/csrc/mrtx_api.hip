@@ -30,6 +30,7 @@ hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, h
 hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float* c, float* lat, float* lon, int n,
                                     hipStream_t st);
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st);
+hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, hipStream_t st);
 
 struct mrtx_ctx {
     MrtxConfig cfg{};
@@ -41,6 +42,7 @@ struct mrtx_ctx {
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
     float* dem = nullptr; int dem_h = 0, dem_w = 0;   // padded (h+4) x (w+4) copy, always owned
+    float* mip = nullptr; int mip_h = 0, mip_w = 0;   // 64x64-texel max-mip of it (+ one-cell border)
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
     unsigned long long* stats_dev = nullptr;
@@ -169,6 +171,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     f.key0 = mix32h(c->prm.seed ^ 0x9E3779B9u);
     for (int i = 0; i < 3; i++) f.const_albedo[i] = c->prm.const_albedo[i];
     f.dem = c->dem; f.color = c->color; f.bg = c->bg;
+    f.mip = c->mip; f.mip_pitch = c->mip_w + 2; f.mip_h = c->mip_h; f.mip_w = c->mip_w;
     f.dem_pitch = c->dem_w + 4;
     f.dem_maxidx = (uint32_t)((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 4) + (uint64_t)(c->dem_w + 2));
     f.dem_wide = ((uint64_t)(c->dem_h + 4) * (uint64_t)(c->dem_w + 4) * 4ull > 0xFFFFFFFFull) ? 1 : 0;
@@ -249,6 +252,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
     if (c->dem) (void)hipFree(c->dem);
+    if (c->mip) (void)hipFree(c->mip);
     if (c->color && c->color_owned) (void)hipFree(c->color);
     if (c->bg) (void)hipFree(c->bg);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -266,6 +270,11 @@ static int ingest_dem(mrtx_ctx* c, const float* dev_src, int32_t h, int32_t w) {
     const size_t bytes = (size_t)(h + 4) * (size_t)(w + 4) * sizeof(float);
     HIPCHK(c, hipMalloc((void**)&c->dem, bytes));
     HIPCHK(c, mrtx_launch_pad_dem(dev_src, c->dem, h, w, c->stream));
+    if (c->mip) { HIPCHK(c, hipFree(c->mip)); }
+    c->mip = nullptr;
+    c->mip_h = (h + 63) / 64; c->mip_w = (w + 63) / 64;
+    HIPCHK(c, hipMalloc((void**)&c->mip, (size_t)(c->mip_h + 2) * (c->mip_w + 2) * sizeof(float)));
+    HIPCHK(c, mrtx_launch_mip(c->dem, h, w, c->mip, c->mip_h, c->mip_w, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dem_h = h; c->dem_w = w;
     return MRTX_OK;
@@ -391,6 +400,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     f.n_blocks = (uint32_t)n_blocks;
     const bool stats = (c->prm.flags & MRTX_F_COUNT_STATS) != 0;
     if (c->prm.flags & MRTX_F_FORCE_WIDE) f.dem_wide = 1;
+    if (c->prm.flags & MRTX_F_NO_SKIP) f.mip = nullptr;
     if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->stream));
@@ -408,6 +418,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
             HIPCHK(c, hipMemcpy(h, c->stats_dev, sizeof h, hipMemcpyDeviceToHost));
             out->primary_rays = h[0]; out->primary_hits = h[1]; out->shadow_rays = h[2];
             out->height_samples = h[3]; out->colour_fetches = h[4]; out->background_fetches = h[5];
+            out->dem_fetches = h[6]; out->mip_fetches = h[7];
         }
     }
     return MRTX_OK;

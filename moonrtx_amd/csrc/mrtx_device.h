@@ -38,6 +38,8 @@ struct FrameC {
     const float* dem;       // PADDED (h+4) x (w+4): element [0] is (row -2, col -2); see dem_march()
     int32_t dem_pitch, dem_wide;   // pitch = w+4 floats; wide = byte offsets need 64 bits (> 4 GiB)
     uint32_t dem_maxidx;           // (h+2)*pitch + (w+2): last padded index a 2x2 tap may start at
+    const float* mip;       // max-mip, (mip_h+2) x (mip_w+2) incl. its border, or null (skipping disabled)
+    int32_t mip_pitch, mip_h, mip_w;
     const uint8_t* color;   // RGBA8 or null
     const uint8_t* bg;      // RGBA8 or null
     // image-tile sharding (new) + accumulation state
@@ -45,5 +47,5 @@ struct FrameC {
     uint32_t first_block, n_blocks;
     float* accum;           // W*H float4: running sums r,g,b,coverage
     float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block
-    unsigned long long* stats;  // 6 counters, see MrtxStats
+    unsigned long long* stats;  // 8 counters, see MrtxStats
 };

@@ -30,7 +30,7 @@ __device__ constexpr float kPi = 3.14159274101257324f;
 __device__ constexpr float kHalfPi = 1.57079637050628662f;
 __device__ constexpr float kInv255 = 0.003921568859368563f;
 
-enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_N };
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_FETCH, ST_MIP, ST_N };
 
 // atan(q) ~= q * P(q^2) on [0,1], |err| <= 1.3e-7
 __device__ __forceinline__ float atan_poly(float q) {
@@ -183,10 +183,14 @@ __device__ __forceinline__ Tap grid_tap(const GridC& g, float rowf, float colf) 
 // i.e. the float32 resolution of the coordinate itself).  Segments that touch the polar cap or straddle
 // the +/-180 seam evaluate every step exactly.  DEM evaluations, hit tests and counters are unchanged.
 constexpr int SEG_N = 16;
+constexpr int MIP_SHIFT = 6;   // max-mip cell = 64 x 64 texels
 struct Seg {
     float sa, ra, r1, r2, ca, c1, c2;
+    int jlo, jhi;   // steps of this segment that can possibly be at/below the surface (see seg_setup)
     bool exact;
 };
+// per-march constants of r^2(s) = q0 + 2 b s + a s^2
+struct RayQ { float q0, b, a; };
 
 __device__ __forceinline__ void exact_rowcol(const FrameC& f, float pa, float pb, float pc, float& rowf, float& colf,
                                              float& rho2) {
@@ -197,9 +201,17 @@ __device__ __forceinline__ void exact_rowcol(const FrameC& f, float pa, float pb
     colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
 }
 
+// Anchors + quadratic of one segment, and the RESULT-PRESERVING skip interval:
+// the max-mip (64x64-texel cell maxima, ~1 MB, cache resident) bounds D over the footprint of the three
+// anchors (+1 texel for the bilinear tap and the quadratic's bulge): D <= Dmax there.  A step can only be at or
+// below the surface if r^2(s) <= (R Dmax)^2; r^2(s) is a parabola in s, so those steps form one interval
+// [jlo, jhi] (widened by a step each side and by 1e-5 in the bound, which dwarfs every rounding involved,
+// so approximate v_sqrt/v_rcp are fine here).  Steps outside it cannot hit and are not evaluated; the ray's
+// termination test is monotone, so it is enough to apply it at evaluated steps and at the segment end.
+template <bool STATS>
 __device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
-                                          int ka, float rowA, float colA, float q2A, Seg& sg, float& rowB,
-                                          float& colB, float& q2B) {
+                                          const RayQ& rq, int ka, float rowA, float colA, float q2A, Seg& sg,
+                                          float& rowB, float& colB, float& q2B, uint32_t* cnt) {
     const float sm = (float)(ka + SEG_N / 2) * f.step, sb = (float)(ka + SEG_N) * f.step;
     float rM, cM, q2M;
     exact_rowcol(f, fmaf(sm, da, oa), fmaf(sm, db, ob), fmaf(sm, dc, oc), rM, cM, q2M);
@@ -213,6 +225,34 @@ __device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, f
     sg.r1 = fmaf(-16.0f, sg.r2, (rowB - rowA) * 0.0625f);
     sg.c2 = (fmaf(-2.0f, cM, colA) + colB) * 0.0078125f;
     sg.c1 = fmaf(-16.0f, sg.c2, (colB - colA) * 0.0625f);
+
+    sg.jlo = 1; sg.jhi = SEG_N;
+    if (f.mip != nullptr) {
+        const int i0 = ((int)floorf(fminf(rowA, fminf(rM, rowB))) - 1) >> MIP_SHIFT;
+        const int i1 = ((int)floorf(fmaxf(rowA, fmaxf(rM, rowB))) + 2) >> MIP_SHIFT;
+        const int j0 = ((int)floorf(fminf(colA, fminf(cM, colB))) - 1) >> MIP_SHIFT;
+        const int j1 = ((int)floorf(fmaxf(colA, fmaxf(cM, colB))) + 2) >> MIP_SHIFT;
+        const bool usable = !sg.exact & (i1 - i0 <= 1) & (j1 - j0 <= 1) & (i0 >= -1) & (i1 <= f.mip_h) & (j0 >= -1) &
+                            (j1 <= f.mip_w);
+        if (usable) {
+            const float* __restrict__ m = f.mip;
+            const int ra = (i0 + 1) * f.mip_pitch, rb = (i1 + 1) * f.mip_pitch;
+            const float dmax = fmaxf(fmaxf(m[ra + j0 + 1], m[ra + j1 + 1]), fmaxf(m[rb + j0 + 1], m[rb + j1 + 1]));
+            if (STATS) cnt[ST_MIP] += 4;
+            const float rd = f.Rf * dmax;
+            const float T = (rd * rd) * 1.00001f;
+            const float disc = fmaf(rq.b, rq.b, -rq.a * (rq.q0 - T));
+            if (disc < 0.0f) {
+                sg.jlo = SEG_N + 1; sg.jhi = SEG_N;      // the whole segment stays above Dmax
+            } else {
+                const float sq = __builtin_amdgcn_sqrtf(disc), inva = __builtin_amdgcn_rcpf(rq.a);
+                const float u1 = fminf(fmaxf(((-rq.b - sq) * inva - sg.sa) * f.inv_step, -4.0f), 64.0f);
+                const float u2 = fminf(fmaxf(((-rq.b + sq) * inva - sg.sa) * f.inv_step, -4.0f), 64.0f);
+                sg.jlo = min(SEG_N + 1, max(1, (int)floorf(u1) - 1));
+                sg.jhi = min(SEG_N, (int)ceilf(u2) + 1);
+            }
+        }
+    }
 }
 
 // is the point at or below the displaced surface?  r^2 <= (R * D(row, col))^2
@@ -233,48 +273,80 @@ __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float 
     return r2 <= surf * surf;
 }
 
-// The 16 steps of one segment.  Branch-free body: the DEM is sampled even on the step that turns out to lie
-// outside (its result is discarded; at most one wasted sample per ray), so the only control flow is the
-// loop-back on the ballot of lanes still marching.
+// The steps jlo..jhi of one segment, per lane.  Branch-free body: the DEM is sampled even on the step that
+// turns out to lie outside (its result is discarded; at most one wasted sample per ray), so the only control
+// flow is the loop-back on the ballot of lanes still stepping.
 template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE>
 __device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                           float smax, const Seg& sg, int ka, bool& go, bool& hit, float& sk_out,
                                           uint32_t* cnt) {
-    int j = 0;
-    do {
-        j++;
-        const float sk = (float)(ka + j) * f.step;
+    int j = sg.jlo;
+    bool more = j <= sg.jhi;
+    while (more) {
+        const int k = ka + j;
+        const float sk = (float)k * f.step;
         const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
         const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
-        const bool in = PRIMARY ? (sk <= smax) : (r2 <= f.R2f);
+        const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
         const bool bel = below_seg<WIDE, EXACTABLE>(f, sg, sk, pa, pb, pc, r2);
-        if (STATS) cnt[ST_HEIGHT] += in ? 1u : 0u;
+        if (STATS) { cnt[ST_HEIGHT] += in ? 1u : 0u; cnt[ST_FETCH]++; }
         hit = in & bel;
         go = in & !bel;
         sk_out = sk;
-    } while (go && j < SEG_N);
+        j++;
+        more = go & (j <= sg.jhi);
+    }
+}
+
+// STATS builds only: the spec counts a DEM evaluation at every step that is still inside; add the skipped ones.
+template <bool PRIMARY>
+__device__ __forceinline__ uint32_t count_in_steps(const FrameC& f, float oa, float ob, float oc, float da, float db,
+                                                   float dc, float smax, int ka, int j_from, int j_to) {
+    uint32_t n = 0;
+    for (int j = j_from; j <= j_to; j++) {
+        const int k = ka + j;
+        const float sk = (float)k * f.step;
+        const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
+        const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+        const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
+        if (!in) break;
+        n++;
+    }
+    return n;
 }
 
 // Coarse march s_k = k*step, k = 1, 2, ...; returns true and s_k at the first sample at/below the surface.
 // PRIMARY: stop when s_k > smax (left the bounding sphere); shadow rays: stop when r^2 > R^2.
-// All lanes of a wave share k (the step counter lives in an SGPR); a lane drops out of the exec mask when it
-// hits or leaves, and the wave leaves the loop when no lane is still marching.  f.kmax is a multiple of SEG_N.
+// A lane drops out of the exec mask when it hits or leaves, and the wave leaves the loop when no lane is still
+// marching.  f.kmax is a multiple of SEG_N.
 template <bool WIDE, bool PRIMARY, bool STATS>
 __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                       float smax, Seg& sg, float& sk_hit, uint32_t* cnt) {
     float rowA, colA, q2A;
     exact_rowcol(f, oa, ob, oc, rowA, colA, q2A);
+    RayQ rq;
+    rq.q0 = fmaf(oc, oc, q2A);
+    rq.b = fmaf(oc, dc, fmaf(ob, db, oa * da));
+    rq.a = fmaf(dc, dc, fmaf(db, db, da * da));
     bool hit = false, go = true;
     int ka = 0;
     while (go) {
         float rowB, colB, q2B;
-        seg_setup(f, oa, ob, oc, da, db, dc, ka, rowA, colA, q2A, sg, rowB, colB, q2B);
+        seg_setup<STATS>(f, oa, ob, oc, da, db, dc, rq, ka, rowA, colA, q2A, sg, rowB, colB, q2B, cnt);
+        if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, 1, sg.jlo - 1);
         if (__ballot(sg.exact) != 0ull)
             step_loop<WIDE, PRIMARY, STATS, true>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
         else
             step_loop<WIDE, PRIMARY, STATS, false>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+        if (go) {
+            // still marching after the last evaluated step: did the ray end inside the skipped tail?
+            if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, max(sg.jhi + 1, 1), SEG_N);
+            const int k = ka + SEG_N;
+            const float sk = (float)k * f.step;
+            const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
+            go = (PRIMARY ? (sk <= smax) : (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f)) & (k < f.kmax);
+        }
         ka += SEG_N; rowA = rowB; colA = colB; q2A = q2B;
-        go = go & (ka < f.kmax);
     }
     return hit;
 }
@@ -346,7 +418,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
                 hi = bel ? mid : hi;
                 lo = bel ? lo : mid;
             }
-            if (STATS) cnt[ST_HEIGHT] += (uint32_t)f.nbis;
+            if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
         }
     }
 
@@ -399,7 +471,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     const float ds = dem_march<WIDE>(f, rowf + 1.0f, colf);
     const float de = dem_march<WIDE>(f, rowf, colf + 1.0f);
     const float dw = dem_march<WIDE>(f, rowf, colf - 1.0f);
-    if (STATS) cnt[ST_HEIGHT] += 4;
+    if (STATS) { cnt[ST_HEIGHT] += 4; cnt[ST_FETCH] += 4; }
     const float dlat = (dn - ds) * f.dlat_scale;
     const float dlon = (de - dw) * f.dlon_scale;
     const float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
@@ -780,6 +852,28 @@ __global__ void pad_dem_kernel(const float* __restrict__ src, float* __restrict_
     }
 }
 
+// max-mip of the padded DEM: cell (i, j) = max over texel rows [64i-2, 64i+65] (clamped) x columns [64j-2, 64j+65]
+// (wrapped) -- dilated by the two-texel border so that any bilinear tap whose indices land in a cell is covered.
+// Stored with a one-cell border of its own: (mh+2) x (mw+2), rows clamp, columns wrap.
+__global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, int w, float* __restrict__ mip, int mh,
+                                 int mw) {
+    const int pitch = w + 4, mp = mw + 2;
+    const int n = (mh + 2) * mp;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        int i = t / mp - 1, j = t % mp - 1;
+        i = i < 0 ? 0 : (i > mh - 1 ? mh - 1 : i);
+        j = j < 0 ? mw - 1 : (j > mw - 1 ? 0 : j);
+        const int r0 = max(64 * i - 2, -2), r1 = min(64 * i + 65, h + 1);
+        const int c0 = max(64 * j - 2, -2), c1 = min(64 * j + 65, w + 1);
+        float m = 0.0f;
+        for (int r = r0; r <= r1; r++) {
+            const float* row = dem_padded + (int64_t)(r + 2) * pitch + 2;
+            for (int c = c0; c <= c1; c++) m = fmaxf(m, row[c]);
+        }
+        mip[t] = m;
+    }
+}
+
 }  // namespace mrtx
 
 // ------------------------------------------------------------------------------------------------
@@ -857,6 +951,11 @@ hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, h
 hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float* c, float* lat, float* lon, int n,
                                     hipStream_t st) {
     hipLaunchKernelGGL(mrtx::probe_latlon_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, lat, lon, n);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::mip_build_kernel, dim3(grid_for((int64_t)(mh + 2) * (mw + 2))), dim3(256), 0, st, dem_padded,
+                       h, w, mip, mh, mw);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st) {

@@ -92,6 +92,27 @@ def test_ragged_dem_shapes(native_lib):
     check(named_scene("S2", 32, 32, spp_per_launch=4), tiny)
 
 
+def test_maxmip_skip_is_result_preserving(native_lib, dem_small):
+    """The max-mip step skip must change nothing but the number of DEM evaluations performed."""
+    from moonrtx_amd import _lib
+    from moonrtx_amd.renderer import MoonRT
+    for name, spp in (("S1", 16), ("S3", 4)):
+        s = named_scene(name, 120, 90, spp_per_launch=spp)
+        out = {}
+        for tag, flags in (("skip", _lib.F_COUNT_STATS), ("full", _lib.F_COUNT_STATS | _lib.F_NO_SKIP)):
+            rt = MoonRT(s.width, s.height)
+            rt.upload_dem(dem_small); rt.apply_scene(s); rt.set_params(flags=flags)
+            st = rt.render(1)
+            out[tag] = (rt.read_linear(), rt.read_hits(), st)
+            rt.close()
+        assert_bit_equal(out["skip"][0], out["full"][0], "skip vs full radiance")
+        assert_bit_equal(out["skip"][1], out["full"][1], "skip vs full hits")
+        a, b = out["skip"][2], out["full"][2]
+        assert {k: a[k] for k in STAT_KEYS} == {k: b[k] for k in STAT_KEYS}
+        assert b["dem_fetches"] >= b["height_samples"] and b["mip_fetches"] == 0
+        assert a["dem_fetches"] < 0.7 * b["dem_fetches"] and a["mip_fetches"] > 0
+
+
 def test_wide_addressing_path_matches(native_lib, dem_small):
     """DEMs above 4 GiB (downscale 1: 17 GB) take 64-bit byte offsets; force that path on a small DEM."""
     from moonrtx_amd import _lib
