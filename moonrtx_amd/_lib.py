@@ -36,6 +36,7 @@ class MrtxStats(C.Structure):
 F_COUNT_STATS = 1
 F_FORCE_WIDE = 2
 F_NO_SKIP = 4
+F_NO_CULL = 8
 BUF_ACCUM, BUF_HITS, BUF_DEM, BUF_COLOR = 0, 1, 2, 3
 
 _D3 = C.POINTER(C.c_double)

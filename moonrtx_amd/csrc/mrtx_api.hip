@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/moonrt.h"
 #include "mrtx_device.h"
@@ -46,6 +47,7 @@ struct mrtx_ctx {
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
     unsigned long long* stats_dev = nullptr;
+    int32_t* tile_list_dev = nullptr;   // n_local entries
     uint32_t blocks_done = 0;
     double eye[3] = {0, -300, 0}, target[3] = {0, 0, 0}, up[3] = {0, 0, 1}, vfov = 4.2421875;
     double center[3] = {0, 0, 0}, radius = 10.0, u[3] = {0, 0, 1}, v[3] = {0, -1, 0};
@@ -179,6 +181,66 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y;
     f.rank = c->cfg.rank; f.world = c->cfg.world; f.n_local_tiles = c->n_local;
     f.accum = c->accum; f.hits = c->hits; f.stats = c->stats_dev;
+    f.tile_list = nullptr; f.n_active = c->n_local;
+}
+
+// Host-side sky cull (exact): with no environment texture a pixel whose samples all miss the Moon's bounding
+// sphere and the Sun disk is identically zero (radiance, coverage and hit record).  A tile is kept unless the
+// cone of its view directions (tile-centre direction, half-angle = largest corner angle + 5 % + 1e-4 rad, pixel
+// extents included so every jittered sample is inside) is disjoint from both objects' cones as seen from the eye.
+// Returns the local tile indices to render and the number of pixels culled.
+void cull_tiles(const mrtx_ctx* c, std::vector<int32_t>& keep, uint64_t& culled_px) {
+    keep.clear(); culled_px = 0;
+    const int W = c->cfg.width, H = c->cfg.height;
+    double wv[3], uv[3], vv[3];
+    for (int i = 0; i < 3; i++) wv[i] = c->target[i] - c->eye[i];
+    unit3(wv);
+    cross(wv, c->up, uv); unit3(uv);
+    cross(uv, wv, vv);
+    const double th = std::tan(c->vfov * kPiD / 360.0), aspect = (double)W / (double)H;
+    struct Cone { double ax[3]; double half; bool all; bool on; };
+    Cone cones[2];
+    const double* centres[2] = {c->center, c->sun_pos};
+    const double radii[2] = {c->radius, c->sun_radius};
+    for (int k = 0; k < 2; k++) {
+        Cone& cn = cones[k];
+        cn.on = radii[k] > 0.0; cn.all = false; cn.half = 0.0;
+        double d[3] = {centres[k][0] - c->eye[0], centres[k][1] - c->eye[1], centres[k][2] - c->eye[2]};
+        const double dist = std::sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        if (!cn.on) continue;
+        if (dist <= radii[k] * 1.0001) { cn.all = true; continue; }
+        for (int i = 0; i < 3; i++) cn.ax[i] = d[i] / dist;
+        cn.half = std::asin(radii[k] / dist);
+    }
+    const bool everything = c->bg != nullptr || cones[0].all || cones[1].all;
+    auto dir = [&](double px, double py, double o[3]) {
+        const double sx = px * 2.0 / W - 1.0, sy = 1.0 - py * 2.0 / H;
+        for (int i = 0; i < 3; i++) o[i] = wv[i] + sx * (uv[i] * (th * aspect)) + sy * (vv[i] * th);
+        unit3(o);
+    };
+    auto ang = [](const double a[3], const double b[3]) {
+        double dp = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+        dp = dp > 1.0 ? 1.0 : (dp < -1.0 ? -1.0 : dp);
+        return std::acos(dp);
+    };
+    for (int lt = 0; lt < c->n_local; lt++) {
+        const int t = lt * c->cfg.world + c->cfg.rank;
+        const int x0 = (t % c->tiles_x) * c->cfg.tile_w, y0 = (t / c->tiles_x) * c->cfg.tile_h;
+        const int x1 = x0 + c->cfg.tile_w < W ? x0 + c->cfg.tile_w : W, y1 = y0 + c->cfg.tile_h < H ? y0 + c->cfg.tile_h : H;
+        bool need = everything;
+        if (!need) {
+            double d0[3], dc[3];
+            dir(0.5 * (x0 + x1), 0.5 * (y0 + y1), d0);
+            double gamma = 0.0;
+            const double cx[4] = {(double)x0, (double)x1, (double)x0, (double)x1}, cy[4] = {(double)y0, (double)y0, (double)y1, (double)y1};
+            for (int k = 0; k < 4; k++) { dir(cx[k], cy[k], dc); const double a = ang(d0, dc); gamma = a > gamma ? a : gamma; }
+            gamma = gamma * 1.05 + 1.0e-4;
+            for (int k = 0; k < 2; k++)
+                if (cones[k].on && ang(d0, cones[k].ax) <= cones[k].half + gamma) need = true;
+        }
+        if (need) keep.push_back(lt);
+        else culled_px += (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
+    }
 }
 
 int check_vec(const double* p) {
@@ -236,6 +298,7 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
     HIPCHK(c, hipMalloc((void**)&c->hits, fb));
     HIPCHK(c, hipMalloc(&c->scratch, fb));
     HIPCHK(c, hipMalloc((void**)&c->stats_dev, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc((void**)&c->tile_list_dev, (size_t)(c->n_local > 0 ? c->n_local : 1) * sizeof(int32_t)));
     HIPCHK(c, hipMemsetAsync(c->accum, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->hits, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
@@ -251,6 +314,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->hits) (void)hipFree(c->hits);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
+    if (c->tile_list_dev) (void)hipFree(c->tile_list_dev);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
     if (c->color && c->color_owned) (void)hipFree(c->color);
@@ -399,6 +463,25 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     f.first_block = c->blocks_done;
     f.n_blocks = (uint32_t)n_blocks;
     const bool stats = (c->prm.flags & MRTX_F_COUNT_STATS) != 0;
+    uint64_t culled_px = 0;
+    if (!(c->prm.flags & MRTX_F_NO_CULL)) {
+        std::vector<int32_t> keep;
+        cull_tiles(c, keep, culled_px);
+        if ((int)keep.size() < c->n_local) {
+            if (!keep.empty())
+                HIPCHK(c, hipMemcpyAsync(c->tile_list_dev, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            f.tile_list = c->tile_list_dev;
+            f.n_active = (int)keep.size();
+            if (c->blocks_done == 0) {   // culled tiles are all-zero by construction; clear what an earlier view left there
+                const size_t fb = (size_t)c->cfg.width * c->cfg.height * 16;
+                HIPCHK(c, hipMemsetAsync(c->accum, 0, fb, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->hits, 0, fb, c->stream));
+            }
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // `keep` is host memory
+        } else {
+            culled_px = 0;
+        }
+    }
     if (c->prm.flags & MRTX_F_FORCE_WIDE) f.dem_wide = 1;
     if (c->prm.flags & MRTX_F_NO_SKIP) f.mip = nullptr;
     if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
@@ -416,7 +499,8 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
         if (stats) {
             unsigned long long h[8];
             HIPCHK(c, hipMemcpy(h, c->stats_dev, sizeof h, hipMemcpyDeviceToHost));
-            out->primary_rays = h[0]; out->primary_hits = h[1]; out->shadow_rays = h[2];
+            out->primary_rays = h[0] + culled_px * (uint64_t)c->prm.spp_per_launch * (uint64_t)n_blocks;
+            out->primary_hits = h[1]; out->shadow_rays = h[2];
             out->height_samples = h[3]; out->colour_fetches = h[4]; out->background_fetches = h[5];
             out->dem_fetches = h[6]; out->mip_fetches = h[7];
         }

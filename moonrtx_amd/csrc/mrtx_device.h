@@ -44,6 +44,8 @@ struct FrameC {
     const uint8_t* bg;      // RGBA8 or null
     // image-tile sharding (new) + accumulation state
     int32_t tile_w, tile_h, tiles_x, tiles_y, rank, world, n_local_tiles;
+    const int32_t* tile_list;   // local tile indices to render (sky tiles culled on the host), or null = all
+    int32_t n_active;           // entries of tile_list (== n_local_tiles when null)
     uint32_t first_block, n_blocks;
     float* accum;           // W*H float4: running sums r,g,b,coverage
     float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block

@@ -574,8 +574,9 @@ __global__ void __launch_bounds__(256, MRTX_MIN_WAVES) render_kernel(const Frame
     // sub-tiles of one tile back to back.
     const int subs_x = f.tile_w >> 4, subs = subs_x * (f.tile_h >> 4);
     const int b = blockIdx.x, xcd = b & 7, g = b >> 3;
-    const int lt = (g / subs) * 8 + xcd, sub = g % subs;
-    if (lt >= f.n_local_tiles) return;
+    const int li = (g / subs) * 8 + xcd, sub = g % subs;
+    if (li >= f.n_active) return;
+    const int lt = f.tile_list ? f.tile_list[li] : li;
     const int t = lt * f.world + f.rank;
     const int tx = t % f.tiles_x, ty = t / f.tiles_x;
     const int px0 = tx * f.tile_w + (sub % subs_x) * 16, py0 = ty * f.tile_h + (sub / subs_x) * 16;
@@ -881,7 +882,7 @@ __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, in
 extern "C++" {
 hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, hipStream_t st) {
     const int subs = (f.tile_w >> 4) * (f.tile_h >> 4);
-    const int groups = (f.n_local_tiles + 7) / 8;
+    const int groups = (f.n_active + 7) / 8;
     const dim3 grid((unsigned)(groups * subs * 8)), block(256);
     if (grid.x == 0) return hipSuccess;
     const bool wide = f.dem_wide != 0;

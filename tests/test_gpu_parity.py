@@ -113,6 +113,30 @@ def test_maxmip_skip_is_result_preserving(native_lib, dem_small):
         assert a["dem_fetches"] < 0.7 * b["dem_fetches"] and a["mip_fetches"] > 0
 
 
+def test_sky_tile_cull_is_result_preserving(native_lib, dem_small):
+    """Host-side cull of tiles that cannot see the Moon or the Sun disk: same frame, same counters."""
+    from moonrtx_amd import _lib
+    from moonrtx_amd.renderer import MoonRT
+    s = named_scene("S1", 400, 300, spp_per_launch=4)
+    s.sun_pos, s.sun_radius = (150.0, 3100.0 - 300.0, -80.0), 25.0        # a visible Sun disk off to the side
+    out = {}
+    for tag, flags in (("cull", _lib.F_COUNT_STATS), ("all", _lib.F_COUNT_STATS | _lib.F_NO_CULL)):
+        rt = MoonRT(s.width, s.height, tile=(16, 16))
+        rt.upload_dem(dem_small); rt.apply_scene(s); rt.set_params(flags=flags)
+        st = rt.render(1)
+        out[tag] = (rt.read_linear(), rt.read_hits(), st)
+        # a second view through the same context: the cull set changes, stale pixels must not survive
+        rt.set_camera((0.0, -300.0, 0.0), (6.0, 0.0, -5.0), (0, 0, 1), 1.5)
+        rt.reset(); st2 = rt.render(1)
+        out[tag + "2"] = (rt.read_linear(), rt.read_hits(), st2)
+        rt.close()
+    for a, b in (("cull", "all"), ("cull2", "all2")):
+        assert_bit_equal(out[a][0], out[b][0], "cull vs all radiance")
+        assert_bit_equal(out[a][1], out[b][1], "cull vs all hits")
+        assert {k: out[a][2][k] for k in STAT_KEYS} == {k: out[b][2][k] for k in STAT_KEYS}
+    assert out["cull"][0][..., :3].max() >= 2.0 - 1e-6      # the Sun disk is there (radiance 2.0)
+
+
 def test_wide_addressing_path_matches(native_lib, dem_small):
     """DEMs above 4 GiB (downscale 1: 17 GB) take 64-bit byte offsets; force that path on a small DEM."""
     from moonrtx_amd import _lib
