@@ -48,6 +48,11 @@ struct mrtx_ctx {
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
     unsigned long long* stats_dev = nullptr;
     int32_t* tile_list_dev = nullptr;   // n_local entries
+    std::vector<int32_t> keep_uploaded;  // what tile_list_dev holds
+    std::vector<int32_t> keep_cached;    // cull result for scene_version == cull_version
+    uint64_t culled_px_cached = 0;
+    uint64_t scene_version = 1, cull_version = 0;   // bumped by every setter that can change the cull
+    std::vector<uint8_t> tile_dirty;     // local tiles written since the buffers were last zeroed
     uint32_t blocks_done = 0;
     double eye[3] = {0, -300, 0}, target[3] = {0, 0, 0}, up[3] = {0, 0, 1}, vfov = 4.2421875;
     double center[3] = {0, 0, 0}, radius = 10.0, u[3] = {0, 0, 1}, v[3] = {0, -1, 0};
@@ -389,12 +394,14 @@ int mrtx_upload_background(mrtx_ctx* c, const uint8_t* rgba, int32_t h, int32_t 
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (c->bg) { HIPCHK(c, hipFree(c->bg)); }
     c->bg = nullptr; c->bg_h = c->bg_w = 0;
+    c->scene_version++;
     if (!rgba) return MRTX_OK;
     if (h < 1 || w < 1) return fail(c, MRTX_E_INVALID, "background must be (h>=1, w>=1, 4) uint8");
     const size_t bytes = (size_t)h * w * 4;
     HIPCHK(c, hipMalloc((void**)&c->bg, bytes));
     HIPCHK(c, hipMemcpy(c->bg, rgba, bytes, hipMemcpyHostToDevice));
     c->bg_h = h; c->bg_w = w;
+    c->scene_version++;
     return MRTX_OK;
 }
 
@@ -420,6 +427,7 @@ int mrtx_set_camera(mrtx_ctx* c, const double eye[3], const double target[3], co
     if (!((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2] > 0.0)) return fail(c, MRTX_E_INVALID, "camera up is parallel to the view axis");
     for (int i = 0; i < 3; i++) { c->eye[i] = eye[i]; c->target[i] = target[i]; c->up[i] = up[i]; }
     c->vfov = vfov;
+    c->scene_version++;
     return MRTX_OK;
 }
 int mrtx_set_moon_frame(mrtx_ctx* c, const double center[3], double radius, const double u[3], const double v[3]) {
@@ -430,6 +438,7 @@ int mrtx_set_moon_frame(mrtx_ctx* c, const double center[3], double radius, cons
     if (!((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2] > 0.0)) return fail(c, MRTX_E_INVALID, "moon u and v are parallel");
     for (int i = 0; i < 3; i++) { c->center[i] = center[i]; c->u[i] = u[i]; c->v[i] = v[i]; }
     c->radius = radius;
+    c->scene_version++;
     return MRTX_OK;
 }
 int mrtx_set_light(mrtx_ctx* c, const double pos[3], double radius, double radiance) {
@@ -444,6 +453,7 @@ int mrtx_set_sun_disk(mrtx_ctx* c, const double pos[3], double radius, double ra
     if (!check_vec(pos) || !std::isfinite(radius) || !(radiance >= 0.0)) return fail(c, MRTX_E_INVALID, "bad sun disk");
     for (int i = 0; i < 3; i++) c->sun_pos[i] = pos[i];
     c->sun_radius = radius; c->sun_radiance = radiance;
+    c->scene_version++;
     return MRTX_OK;
 }
 
@@ -463,27 +473,46 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     f.first_block = c->blocks_done;
     f.n_blocks = (uint32_t)n_blocks;
     const bool stats = (c->prm.flags & MRTX_F_COUNT_STATS) != 0;
-    uint64_t culled_px = 0;
-    if (!(c->prm.flags & MRTX_F_NO_CULL)) {
-        std::vector<int32_t> keep;
-        cull_tiles(c, keep, culled_px);
-        if ((int)keep.size() < c->n_local) {
-            if (!keep.empty())
-                HIPCHK(c, hipMemcpyAsync(c->tile_list_dev, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            f.tile_list = c->tile_list_dev;
-            f.n_active = (int)keep.size();
-            if (c->blocks_done == 0) {   // culled tiles are all-zero by construction; clear what an earlier view left there
-                const size_t fb = (size_t)c->cfg.width * c->cfg.height * 16;
-                HIPCHK(c, hipMemsetAsync(c->accum, 0, fb, c->stream));
-                HIPCHK(c, hipMemsetAsync(c->hits, 0, fb, c->stream));
-            }
-            HIPCHK(c, hipStreamSynchronize(c->stream));   // `keep` is host memory
-        } else {
-            culled_px = 0;
-        }
-    }
     if (c->prm.flags & MRTX_F_FORCE_WIDE) f.dem_wide = 1;
     if (c->prm.flags & MRTX_F_NO_SKIP) f.mip = nullptr;
+    uint64_t culled_px = 0;
+    if (c->tile_dirty.size() != (size_t)c->n_local) c->tile_dirty.assign((size_t)c->n_local, 0);
+    bool culling = false;
+    if (!(c->prm.flags & MRTX_F_NO_CULL)) {
+        if (c->cull_version != c->scene_version) {
+            cull_tiles(c, c->keep_cached, c->culled_px_cached);
+            c->cull_version = c->scene_version;
+        }
+        culled_px = c->culled_px_cached;
+        culling = (int)c->keep_cached.size() < c->n_local;
+    }
+    const std::vector<int32_t>& keep = c->keep_cached;
+    if (culling) {
+        if (keep != c->keep_uploaded) {
+            if (!keep.empty()) {
+                HIPCHK(c, hipMemcpyAsync(c->tile_list_dev, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));   // `keep` is pageable host memory
+            }
+            c->keep_uploaded = keep;
+        }
+        f.tile_list = c->tile_list_dev;
+        f.n_active = (int)keep.size();
+        // culled tiles are all-zero by construction: clear only if an earlier view rendered into one of them
+        std::vector<uint8_t> kept((size_t)c->n_local, 0);
+        for (int32_t lt : keep) kept[(size_t)lt] = 1;
+        bool stale = false;
+        for (int lt = 0; lt < c->n_local && !stale; lt++) stale = c->tile_dirty[(size_t)lt] && !kept[(size_t)lt];
+        if (stale) {
+            const size_t fb = (size_t)c->cfg.width * c->cfg.height * 16;
+            HIPCHK(c, hipMemsetAsync(c->accum, 0, fb, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->hits, 0, fb, c->stream));
+            c->tile_dirty.assign((size_t)c->n_local, 0);
+        }
+        for (int32_t lt : keep) c->tile_dirty[(size_t)lt] = 1;
+    } else {
+        culled_px = 0;
+        c->tile_dirty.assign((size_t)c->n_local, 1);
+    }
     if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->stream));
