@@ -187,6 +187,10 @@ def main():
         px_adj = -32 * W * H + 32 * W * H // world
         ach = (algorithmic_bytes(counted, W, H) + px_adj) / (kernel_ms * 1e-3) / 1e9
         ach_nom = (algorithmic_bytes(counted, W, H, nominal=True) + px_adj) / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if world == 1 and args.workload == "cfg3" and os.path.isfile(tpath):
+            traffic = json.load(open(tpath))   # from the rocprofv3 --pmc passes of this same command (tools/profile_bench.sh)
         out = {
             "metric": "Mrays/s (primary camera samples) at 3840x2160, 64 spp, downscale-2 DEM" if args.workload == "cfg3"
                       else f"Mrays/s (primary camera samples), {args.workload}",
@@ -205,7 +209,10 @@ def main():
             "bytes_per_ray": round(algorithmic_bytes(frame, W, H) / rays, 2),
             "bytes_per_ray_nominal": round(algorithmic_bytes(frame, W, H, nominal=True) / rays, 2),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": None if traffic is None else round(traffic["hbm_bytes_per_launch"]),
+                         "traffic_source": None if traffic is None else f"profiles/{traffic['tag']}_summary.md: FETCH_SIZE x {traffic['fetch_factor']} (calibrated on a known 8-byte-per-lane stream) + WRITE_SIZE",
+                         "algorithmic_bytes": int(algorithmic_bytes(counted, W, H) + px_adj),
                          "kernel": "mrtx::render_kernel<64,false,false>",
                          "achieved_nominal": round(ach_nom, 1), "frac_nominal": round(ach_nom / HBM_PEAK_GBS, 4),
                          "note": "achieved = algorithmic bytes / HIP-event launch duration, bytes = 16 B per DEM "

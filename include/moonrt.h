@@ -183,6 +183,10 @@ int mrtx_dev_free(int32_t device, void* p);
 int mrtx_dev_download(int32_t device, void* host_dst, const void* dev_src, uint64_t bytes);
 int mrtx_dev_upload(int32_t device, void* dev_dst, const void* host_src, uint64_t bytes);
 
+/* Profiling aid: streams a `bytes`-sized buffer `repeats` times with 8-byte-per-lane loads (the render kernel's
+ * access width) so rocprofv3's FETCH_SIZE can be calibrated against a known byte count. */
+int mrtx_probe_stream(int32_t device, uint64_t bytes, int32_t repeats);
+
 /* Math conformance probe: evaluates the renderer's own (lat, lon) primitive -- polynomial atan2 pair sharing
  * one reciprocal -- on the device for n moon-frame points (tests compare it with the oracle bit for bit). */
 int mrtx_probe_latlon(int32_t device, const float* a, const float* b, const float* c, float* lat, float* lon,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "mrtx_dev_free": (C.c_int, [C.c_int32, _VP]),
     "mrtx_dev_download": (C.c_int, [C.c_int32, _VP, _VP, C.c_uint64]),
     "mrtx_dev_upload": (C.c_int, [C.c_int32, _VP, _VP, C.c_uint64]),
+    "mrtx_probe_stream": (C.c_int, [C.c_int32, C.c_uint64, C.c_int32]),
     "mrtx_probe_latlon": (C.c_int, [C.c_int32, _VP, _VP, _VP, _VP, _VP, C.c_int32]),
 }
 

@@ -32,6 +32,7 @@ hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float*
                                     hipStream_t st);
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st);
 hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, hipStream_t st);
+hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out, hipStream_t st);
 
 struct mrtx_ctx {
     MrtxConfig cfg{};
@@ -667,6 +668,20 @@ int mrtx_dev_upload(int32_t device, void* dev_dst, const void* host_src, uint64_
     if (!dev_dst || !host_src) return MRTX_E_INVALID;
     if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
     return hipMemcpy(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice) == hipSuccess ? MRTX_OK : MRTX_E_DEVICE;
+}
+int mrtx_probe_stream(int32_t device, uint64_t bytes, int32_t repeats) {
+    if (bytes < 1024 || repeats < 1) return MRTX_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
+    void* buf = nullptr; float* out = nullptr;
+    int rc = MRTX_OK;
+    if (hipMalloc(&buf, (size_t)bytes) != hipSuccess || hipMalloc((void**)&out, 4) != hipSuccess) rc = MRTX_E_NOMEM;
+    if (rc == MRTX_OK && hipMemset(buf, 1, (size_t)bytes) != hipSuccess) rc = MRTX_E_DEVICE;
+    for (int i = 0; i < repeats && rc == MRTX_OK; i++)
+        if (mrtx_launch_probe_stream(buf, (int64_t)(bytes / 8), out, nullptr) != hipSuccess) rc = MRTX_E_DEVICE;
+    if (rc == MRTX_OK && hipDeviceSynchronize() != hipSuccess) rc = MRTX_E_DEVICE;
+    if (buf) (void)hipFree(buf);
+    if (out) (void)hipFree(out);
+    return rc;
 }
 int mrtx_probe_latlon(int32_t device, const float* a, const float* b, const float* c, float* lat, float* lon,
                       int32_t n) {

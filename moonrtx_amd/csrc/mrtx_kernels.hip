@@ -853,6 +853,17 @@ __global__ void pad_dem_kernel(const float* __restrict__ src, float* __restrict_
     }
 }
 
+// FETCH_SIZE calibration (MI355X_MICROARCH.md, HBM section): stream a buffer once with this kernel's own access width
+// (one 8-byte load per lane) so the PMC reading can be compared with a known byte count.
+__global__ void probe_stream_kernel(const Pair* __restrict__ src, int64_t n_pairs, float* __restrict__ out) {
+    float acc = 0.0f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * blockDim.x) {
+        const Pair p = src[i];
+        acc += p.x + p.y;
+    }
+    if (acc == 123456.789f) out[0] = acc;   // keep the loads alive
+}
+
 // max-mip of the padded DEM: cell (i, j) = max over texel rows [64i-2, 64i+65] (clamped) x columns [64j-2, 64j+65]
 // (wrapped) -- dilated by the two-texel border so that any bilinear tap whose indices land in a cell is covered.
 // Stored with a one-cell border of its own: (mh+2) x (mw+2), rows clamp, columns wrap.
@@ -952,6 +963,10 @@ hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, h
 hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float* c, float* lat, float* lon, int n,
                                     hipStream_t st) {
     hipLaunchKernelGGL(mrtx::probe_latlon_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, lat, lon, n);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::probe_stream_kernel, dim3(8192), dim3(256), 0, st, reinterpret_cast<const mrtx::Pair*>(src), n_pairs, out);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, hipStream_t st) {

@@ -50,4 +50,22 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
     if "GRBM_GUI_ACTIVE" in m and "SQ_ACTIVE_INST_ANY" in m:
         cyc = m["GRBM_GUI_ACTIVE"] / 8
         o.write(f"- kernel cycles (GRBM_GUI_ACTIVE/8) = {cyc:.4g}; issue occupancy of the 1024 SIMDs = {m['SQ_ACTIVE_INST_ANY']*4/1024/cyc:.2f}\n")
+# FETCH_SIZE calibration on a known 8-byte-per-lane stream (tools/calibrate_fetch.py: 4 GiB per dispatch)
+cal = []
+for f in glob.glob(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "probe_stream_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+            cal.append(float(r["Counter_Value"]))
+traffic = None
+if cal and "FETCH_SIZE" in m:
+    reported = sum(cal) / len(cal) * 1024.0
+    factor = (4 << 30) / reported
+    traffic = {"fetch_factor": round(factor, 4), "calibration": "4 GiB streamed with 8-byte-per-lane loads, FETCH_SIZE reported %.4g B" % reported,
+               "hbm_read_bytes_per_launch": m["FETCH_SIZE"] * 1024.0 * factor,
+               "hbm_write_bytes_per_launch": m.get("WRITE_SIZE", 0.0) * 1024.0, "tag": tag}
+    traffic["hbm_bytes_per_launch"] = traffic["hbm_read_bytes_per_launch"] + traffic["hbm_write_bytes_per_launch"]
+    json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+    with open(os.path.join(dst, f"{tag}_summary.md"), "a") as o:
+        o.write(f"- FETCH_SIZE calibration (8-byte-per-lane stream of 4 GiB): factor {factor:.3f} => HBM read "
+                f"{traffic['hbm_read_bytes_per_launch']/1e9:.2f} GB + write {traffic['hbm_write_bytes_per_launch']/1e9:.2f} GB per launch\n")
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())
