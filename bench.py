@@ -118,6 +118,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     dev = local
     torch.cuda.set_device(dev)
+    backend = torch.distributed.get_backend() if world > 1 else None
 
     W, H, spp, dem_h, dem_w, col_shape = WORKLOADS[args.workload]
     dem_h //= args.dem_scale
@@ -170,10 +171,11 @@ def main():
     kernel_ms /= max(1, args.steps)
 
     # whole-job numbers: max time over ranks, counts summed over ranks
-    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if backend == "gloo" else "cuda"
+    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
     keys = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches", "background_fetches",
             "dem_fetches", "mip_fetches")
-    cnt = torch.tensor([counted[k] for k in keys], dtype=torch.int64, device="cuda")
+    cnt = torch.tensor([counted[k] for k in keys], dtype=torch.int64, device=red_dev)
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.SUM)

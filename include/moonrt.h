@@ -160,6 +160,8 @@ int mrtx_samples_done(mrtx_ctx* ctx, uint32_t* out);
 int mrtx_shard_bytes(mrtx_ctx* ctx, int32_t rank, uint64_t* out);   /* size of rank's packed buffer */
 int mrtx_pack_shard(mrtx_ctx* ctx, void* dev_dst, void* hip_stream);
 int mrtx_unpack_shard(mrtx_ctx* ctx, int32_t src_rank, const void* dev_src, void* hip_stream);
+/* Same for every peer at once: dev_srcs[r] is rank r's packed buffer (entry 0 is ignored); one synchronisation. */
+int mrtx_unpack_all(mrtx_ctx* ctx, const void* const* dev_srcs, int32_t n);
 
 /* Raw device pointers of the context's buffers (for zero-copy wrapping by the host side). */
 enum { MRTX_BUF_ACCUM = 0, MRTX_BUF_HITS = 1, MRTX_BUF_DEM = 2, MRTX_BUF_COLOR = 3 };

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mrtx_shard_bytes": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64)]),
     "mrtx_pack_shard": (C.c_int, [_VP, _VP, _VP]),
     "mrtx_unpack_shard": (C.c_int, [_VP, C.c_int32, _VP, _VP]),
+    "mrtx_unpack_all": (C.c_int, [_VP, C.POINTER(_VP), C.c_int32]),
     "mrtx_device_ptr": (C.c_int, [_VP, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     "mrtx_dem_from_ldem": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32, _VP,
                                      C.POINTER(C.c_float), C.c_char_p, C.c_int32]),

@@ -596,6 +596,18 @@ int mrtx_unpack_shard(mrtx_ctx* c, int32_t src_rank, const void* dev_src, void* 
     return MRTX_OK;
 }
 
+int mrtx_unpack_all(mrtx_ctx* c, const void* const* dev_srcs, int32_t n) {
+    if (!c || !dev_srcs || n != c->cfg.world) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    for (int r = 1; r < n; r++) {
+        if (!dev_srcs[r]) return fail(c, MRTX_E_INVALID, "missing shard of rank %d", r);
+        HIPCHK(c, mrtx_launch_unpack(c->accum, c->hits, dev_srcs[r], c->cfg.width, c->cfg.height, c->cfg.tile_w,
+                                     c->cfg.tile_h, c->tiles_x, c->n_tiles, r, c->cfg.world, c->slots, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MRTX_OK;
+}
+
 int mrtx_device_ptr(mrtx_ctx* c, int32_t which, void** out, uint64_t* bytes) {
     if (!c || !out) return MRTX_E_INVALID;
     const uint64_t fb = (uint64_t)c->cfg.width * c->cfg.height * 16;

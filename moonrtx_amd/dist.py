@@ -27,14 +27,19 @@ def env_rank_world():
 
 
 def init_process_group(backend=None):
-    """Join the group torchrun described in the environment (MASTER_ADDR must be 127.0.0.1 on one node)."""
+    """Join the group torchrun described in the environment (MASTER_ADDR must be 127.0.0.1 on one node).
+
+    MOONRT_DIST_BACKEND=gloo + MOONRT_ONE_DEVICE=1 rehearse the multi-rank path on a single-GPU box (every rank
+    renders on device 0, the gather is staged through host memory); production is one rank per GPU over RCCL."""
     import torch
     import torch.distributed as dist
     rank, world, local = env_rank_world()
+    if os.environ.get("MOONRT_ONE_DEVICE") == "1":
+        local = 0
     if world == 1:
         return rank, world, local
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("MOONRT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():
@@ -58,6 +63,14 @@ class FrameGather:
         self.recv = None
         if self.rank == 0 and self.world > 1:
             self.recv = [torch.empty_like(self.send) for _ in range(self.world)]
+        # gloo cannot gather device tensors: stage through host memory (rehearsal / CPU tests only)
+        self.host_staged = False
+        if self.world > 1 and self.send.is_cuda:
+            import torch.distributed as dist
+            self.host_staged = dist.get_backend() == "gloo"
+        if self.host_staged:
+            self.send_h = torch.empty(self.nbytes // 4, dtype=torch.float32, pin_memory=True)
+            self.recv_h = [torch.empty(self.nbytes // 4, dtype=torch.float32) for _ in range(self.world)] if self.rank == 0 else None
 
     def gather(self):
         """After every rank has rendered: bring all tiles to rank 0's framebuffer."""
@@ -66,9 +79,19 @@ class FrameGather:
         import torch.distributed as dist
         torch = self.torch
         self.r.pack_shard(self.send.data_ptr())          # synchronous on the renderer's stream
-        dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
+        if self.host_staged:
+            self.send_h.copy_(self.send)
+            dist.gather(self.send_h, self.recv_h if self.rank == 0 else None, dst=0)
+            if self.rank == 0:
+                for src in range(1, self.world):
+                    self.recv[src].copy_(self.recv_h[src])
+        else:
+            dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
         if self.send.is_cuda:
             torch.cuda.synchronize()
         if self.rank == 0:
-            for src in range(1, self.world):
-                self.r.unpack_shard(src, self.recv[src].data_ptr())
+            if hasattr(self.r, "unpack_all"):
+                self.r.unpack_all([t.data_ptr() for t in self.recv])
+            else:
+                for src in range(1, self.world):
+                    self.r.unpack_shard(src, self.recv[src].data_ptr())

@@ -209,6 +209,11 @@ class MoonRT:
     def unpack_shard(self, src_rank, dev_ptr, stream=None):
         self._check(self._lib.mrtx_unpack_shard(self._ctx, int(src_rank), dev_ptr, stream), "mrtx_unpack_shard")
 
+    def unpack_all(self, dev_ptrs):
+        """dev_ptrs[r] = device address of rank r's packed shard (entry 0 ignored); one sync for all peers."""
+        arr = (C.c_void_p * len(dev_ptrs))(*[C.c_void_p(p) for p in dev_ptrs])
+        self._check(self._lib.mrtx_unpack_all(self._ctx, arr, len(dev_ptrs)), "mrtx_unpack_all")
+
     def device_ptr(self, which):
         p, n = C.c_void_p(), C.c_uint64()
         self._check(self._lib.mrtx_device_ptr(self._ctx, which, C.byref(p), C.byref(n)), "mrtx_device_ptr")
