@@ -48,6 +48,7 @@ struct mrtx_ctx {
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
     unsigned long long* stats_dev = nullptr;
+    FrameCold* cold_dev = nullptr;
     int32_t* tile_list_dev = nullptr;   // n_local entries
     std::vector<int32_t> keep_uploaded;  // what tile_list_dev holds
     std::vector<int32_t> keep_cached;    // cull result for scene_version == cull_version
@@ -111,8 +112,9 @@ void set_grid(GridC& g, int h, int w) {
 
 // Scene (float64) -> per-launch constants.  DESIGN.md section 3.1 lists every formula; the oracle
 // derives the same block on its own and tests compare the two float for float.
-void build_frame(const mrtx_ctx* c, FrameC& f) {
+void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     std::memset(&f, 0, sizeof f);
+    std::memset(&k, 0, sizeof k);
     f.W = c->cfg.width; f.H = c->cfg.height;
     double wv[3], uv[3], vv[3];
     for (int i = 0; i < 3; i++) wv[i] = c->target[i] - c->eye[i];
@@ -122,16 +124,16 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     const double th = std::tan(c->vfov * kPiD / 360.0);
     const double aspect = (double)f.W / (double)f.H;
     for (int i = 0; i < 3; i++) {
-        f.Wd[i] = (float)wv[i];
-        f.Ux[i] = (float)(uv[i] * (th * aspect));
-        f.Vy[i] = (float)(vv[i] * th);
-        f.oc[i] = c->eye[i] - c->center[i];
-        f.centerf[i] = (float)c->center[i];
-        f.eyef[i] = (float)c->eye[i];
+        k.Wd[i] = (float)wv[i];
+        k.Ux[i] = (float)(uv[i] * (th * aspect));
+        k.Vy[i] = (float)(vv[i] * th);
+        k.oc[i] = c->eye[i] - c->center[i];
+        k.centerf[i] = (float)c->center[i];
+        k.eyef[i] = (float)c->eye[i];
     }
-    f.two_over_w = (float)(2.0 / (double)f.W);
-    f.two_over_h = (float)(2.0 / (double)f.H);
-    f.cq = ((f.oc[0] * f.oc[0] + f.oc[1] * f.oc[1]) + f.oc[2] * f.oc[2]) - c->radius * c->radius;
+    k.two_over_w = (float)(2.0 / (double)f.W);
+    k.two_over_h = (float)(2.0 / (double)f.H);
+    k.cq = ((k.oc[0] * k.oc[0] + k.oc[1] * k.oc[1]) + k.oc[2] * k.oc[2]) - c->radius * c->radius;
     // moon frame rows: east-90, lon-0, north.  u = north pole, v = longitude-0 direction
     // (moon_renderer.py:621, :844-845; renderer_navigation.py:47-53)
     double ez[3] = {c->u[0], c->u[1], c->u[2]}, v0[3], ex[3];
@@ -140,45 +142,45 @@ void build_frame(const mrtx_ctx* c, FrameC& f) {
     for (int i = 0; i < 3; i++) v0[i] = c->v[i] - dp * ez[i];
     unit3(v0);
     cross(ez, v0, ex);
-    for (int j = 0; j < 3; j++) { f.M[0][j] = ex[j]; f.M[1][j] = v0[j]; f.M[2][j] = ez[j]; }
+    for (int j = 0; j < 3; j++) { k.M[0][j] = ex[j]; k.M[1][j] = v0[j]; k.M[2][j] = ez[j]; }
     for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) f.Mf[i][j] = (float)f.M[i][j];
+        for (int j = 0; j < 3; j++) k.Mf[i][j] = (float)k.M[i][j];
     f.Rf = (float)c->radius;
     f.R2f = f.Rf * f.Rf;
     double lr[3];
     for (int i = 0; i < 3; i++) lr[i] = c->light_pos[i] - c->center[i];
-    for (int i = 0; i < 3; i++) f.Lb[i] = (float)((f.M[i][0] * lr[0] + f.M[i][1] * lr[1]) + f.M[i][2] * lr[2]);
-    f.rL2 = (float)(c->light_radius * c->light_radius);
-    f.rad2 = (float)(2.0 * c->light_radiance);
-    f.sun_on = c->sun_radius > 0.0 ? 1 : 0;
+    for (int i = 0; i < 3; i++) k.Lb[i] = (float)((k.M[i][0] * lr[0] + k.M[i][1] * lr[1]) + k.M[i][2] * lr[2]);
+    k.rL2 = (float)(c->light_radius * c->light_radius);
+    k.rad2 = (float)(2.0 * c->light_radiance);
+    k.sun_on = c->sun_radius > 0.0 ? 1 : 0;
     double sr[3];
-    for (int i = 0; i < 3; i++) { sr[i] = c->sun_pos[i] - c->eye[i]; f.sc[i] = (float)sr[i]; }
-    f.sun_cq = (float)(((sr[0] * sr[0] + sr[1] * sr[1]) + sr[2] * sr[2]) - c->sun_radius * c->sun_radius);
-    f.sun_rad = (float)c->sun_radiance;
+    for (int i = 0; i < 3; i++) { sr[i] = c->sun_pos[i] - c->eye[i]; k.sc[i] = (float)sr[i]; }
+    k.sun_cq = (float)(((sr[0] * sr[0] + sr[1] * sr[1]) + sr[2] * sr[2]) - c->sun_radius * c->sun_radius);
+    k.sun_rad = (float)c->sun_radiance;
     f.step = c->prm.marching_step;
-    f.eps = c->prm.marching_step_eps;
-    f.scene_eps = c->prm.scene_epsilon;
+    k.eps = c->prm.marching_step_eps;
+    k.scene_eps = c->prm.scene_epsilon;
     f.nbis = 0;
-    for (double wdt = (double)f.step; wdt > (double)f.eps && f.nbis < 24; wdt *= 0.5) f.nbis++;
+    for (double wdt = (double)f.step; wdt > (double)k.eps && f.nbis < 24; wdt *= 0.5) f.nbis++;
     f.kmax = (((int)(2.0 * c->radius / (double)f.step) + 8) + 15) & ~15;   // multiple of the 16-step segment
     f.inv_step = 1.0f / f.step;
     f.polar_rho2 = (float)(0.04 * c->radius * c->radius);
     f.row_hi = std::nextafterf((float)c->dem_h, 0.0f);
     f.col_hi = std::nextafterf((float)c->dem_w, 0.0f);
     set_grid(f.gd, c->dem_h, c->dem_w);
-    f.dlat_scale = (float)((double)c->dem_h / (2.0 * kPiD));
-    f.dlon_scale = (float)((double)c->dem_w / (4.0 * kPiD));
-    if (c->color) set_grid(f.gc, c->color_h, c->color_w);
+    k.dlat_scale = (float)((double)c->dem_h / (2.0 * kPiD));
+    k.dlon_scale = (float)((double)c->dem_w / (4.0 * kPiD));
+    if (c->color) set_grid(k.gc, c->color_h, c->color_w);
     if (c->bg) {
-        f.bg_h = c->bg_h; f.bg_w = c->bg_w;
-        f.bg_row_scale = (float)(-(double)c->bg_h / kPiD);
-        f.bg_row_off = (float)(0.5 * (double)c->bg_h);
-        f.bg_col_scale = (float)((double)c->bg_w / (2.0 * kPiD));
-        f.bg_col_off = (float)(0.5 * (double)c->bg_w);
+        k.bg_h = c->bg_h; k.bg_w = c->bg_w;
+        k.bg_row_scale = (float)(-(double)c->bg_h / kPiD);
+        k.bg_row_off = (float)(0.5 * (double)c->bg_h);
+        k.bg_col_scale = (float)((double)c->bg_w / (2.0 * kPiD));
+        k.bg_col_off = (float)(0.5 * (double)c->bg_w);
     }
-    f.key0 = mix32h(c->prm.seed ^ 0x9E3779B9u);
-    for (int i = 0; i < 3; i++) f.const_albedo[i] = c->prm.const_albedo[i];
-    f.dem = c->dem; f.color = c->color; f.bg = c->bg;
+    k.key0 = mix32h(c->prm.seed ^ 0x9E3779B9u);
+    for (int i = 0; i < 3; i++) k.const_albedo[i] = c->prm.const_albedo[i];
+    f.dem = c->dem; k.color = c->color; k.bg = c->bg;
     f.mip = c->mip; f.mip_pitch = c->mip_w + 2; f.mip_h = c->mip_h; f.mip_w = c->mip_w;
     f.dem_pitch = c->dem_w + 4;
     f.dem_maxidx = (uint32_t)((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 4) + (uint64_t)(c->dem_w + 2));
@@ -304,6 +306,7 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
     HIPCHK(c, hipMalloc((void**)&c->hits, fb));
     HIPCHK(c, hipMalloc(&c->scratch, fb));
     HIPCHK(c, hipMalloc((void**)&c->stats_dev, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc((void**)&c->cold_dev, sizeof(FrameCold)));
     HIPCHK(c, hipMalloc((void**)&c->tile_list_dev, (size_t)(c->n_local > 0 ? c->n_local : 1) * sizeof(int32_t)));
     HIPCHK(c, hipMemsetAsync(c->accum, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->hits, 0, fb, c->stream));
@@ -320,6 +323,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->hits) (void)hipFree(c->hits);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
+    if (c->cold_dev) (void)hipFree(c->cold_dev);
     if (c->tile_list_dev) (void)hipFree(c->tile_list_dev);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
@@ -470,7 +474,10 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     if (!c->dem) return fail(c, MRTX_E_STATE, "no displacement map: call mrtx_upload_dem first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     FrameC f;
-    build_frame(c, f);
+    FrameCold cold;
+    build_frame(c, f, cold);
+    f.cold = c->cold_dev;
+    HIPCHK(c, hipMemcpyAsync(c->cold_dev, &cold, sizeof cold, hipMemcpyHostToDevice, c->stream));
     f.first_block = c->blocks_done;
     f.n_blocks = (uint32_t)n_blocks;
     const bool stats = (c->prm.flags & MRTX_F_COUNT_STATS) != 0;

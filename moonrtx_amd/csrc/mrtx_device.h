@@ -1,9 +1,14 @@
 // mrtx_device.h -- data shared by the host side of libmoonrt.so and its gfx950 kernels.
 //
-// FrameC is the per-launch constant block: everything the kernels need, derived once on the host in
-// float64 from the calls the reference makes on its renderer object (moon_renderer.py:570-650 for the
-// static scene, :824-871 for the per-time-step update) and handed to the kernel BY VALUE, so the
-// compiler keeps it in SGPRs (wave-uniform scalar loads, no VGPR cost).
+// Per-launch constants, derived once on the host in float64 from the calls the reference makes on its renderer
+// object (moon_renderer.py:570-650 for the static scene, :824-871 for the per-time-step update).
+//   FrameC    -- what the march loops touch, passed to the kernel BY VALUE -> SGPRs (wave-uniform scalar
+//                loads, no VGPR cost);
+//   FrameCold -- what a sample touches once (camera / moon-frame matrices in float64, light, Sun disk, colour and
+//                environment grids), kept in device memory behind FrameC::cold and read with scalar loads at the
+//                point of use.  Keeping these out of the by-value block stops the compiler from holding ~150
+//                SGPRs live from kernel entry (it spilled 81 of them into VGPR lanes and moved them back and forth
+//                with v_readlane / v_writelane around every sample).
 #pragma once
 #include <stdint.h>
 
@@ -12,36 +17,42 @@ struct GridC {          // equirectangular grid: row 0 = +90 deg, column 0 = -18
     float row_scale, row_off, col_scale, col_off, wf;
 };
 
-struct FrameC {
-    int32_t W, H;
+struct FrameCold {
     // D1 pinhole camera (moon_renderer.py:627-635)
     float Wd[3], Ux[3], Vy[3], two_over_w, two_over_h;
     double oc[3], cq;       // eye - centre, |oc|^2 - R^2
     double M[3][3];         // scene -> moon frame, rows = (east 90, lon 0, north)
     float Mf[3][3], centerf[3], eyef[3];
-    float Rf, R2f;
     // D5 light (moon_renderer.py:640-641, :859-860)
     float Lb[3], rL2, rad2;
     // D8 Sun disk (moon_renderer.py:647-650)
     int32_t sun_on;
     float sc[3], sun_cq, sun_rad;
-    // D2 march (moon_renderer.py:586-588)
-    float step, eps, scene_eps, inv_step;
-    float polar_rho2, row_hi, col_hi;   // segment fallback threshold (0.04 R^2); largest floats below h / w
-    int32_t nbis, kmax;
+    float eps, scene_eps;
     float dlat_scale, dlon_scale;
-    GridC gd, gc;
+    GridC gc;
     int32_t bg_h, bg_w;
     float bg_row_scale, bg_row_off, bg_col_scale, bg_col_off;
     uint32_t key0;
     float const_albedo[3];
+    const uint8_t* color;   // RGBA8 or null
+    const uint8_t* bg;      // RGBA8 or null
+};
+
+struct FrameC {
+    int32_t W, H;
+    float Rf, R2f;
+    // D2 march (moon_renderer.py:586-588)
+    float step, inv_step;
+    float polar_rho2, row_hi, col_hi;   // segment fallback threshold (0.04 R^2); largest floats below h / w
+    int32_t nbis, kmax;
+    GridC gd;
     const float* dem;       // PADDED (h+4) x (w+4): element [0] is (row -2, col -2); see dem_march()
     int32_t dem_pitch, dem_wide;   // pitch = w+4 floats; wide = byte offsets need 64 bits (> 4 GiB)
     uint32_t dem_maxidx;           // (h+2)*pitch + (w+2): last padded index a 2x2 tap may start at
     const float* mip;       // max-mip, (mip_h+2) x (mip_w+2) incl. its border, or null (skipping disabled)
     int32_t mip_pitch, mip_h, mip_w;
-    const uint8_t* color;   // RGBA8 or null
-    const uint8_t* bg;      // RGBA8 or null
+    const FrameCold* cold;  // device memory
     // image-tile sharding (new) + accumulation state
     int32_t tile_w, tile_h, tiles_x, tiles_y, rank, world, n_local_tiles;
     const int32_t* tile_list;   // local tile indices to render (sky tiles culled on the host), or null = all

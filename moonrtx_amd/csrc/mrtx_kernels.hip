@@ -24,6 +24,10 @@
 
 #include "mrtx_device.h"
 
+// The cold constants are read-only for the whole launch: address them through the constant address space so the
+// (wave-uniform) reads become scalar loads (s_load_*) instead of per-lane vector loads.
+#define CF(f) ((const __attribute__((address_space(4))) FrameCold*)(f).cold)
+
 namespace mrtx {
 
 __device__ constexpr float kPi = 3.14159274101257324f;
@@ -360,7 +364,7 @@ template <bool STATS, bool WIDE>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
-    const uint32_t kp = mix32(pix + f.key0);
+    const uint32_t kp = mix32(pix + CF(f)->key0);
     const uint32_t ks = mix32(kp ^ (gs * 0x85EBCA6Bu + 1u));
     const float u0 = u01(ks, 0), u1 = u01(ks, 1), u2 = u01(ks, 2), u3 = u01(ks, 3);
     o.c0 = o.c1 = o.c2 = 0.0f; o.hitflag = 0.0f;
@@ -369,19 +373,19 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
 
     // D1: jittered pinhole ray
     const float fx = (float)x + u0, fy = (float)y + u1;
-    const float sx = fmaf(fx, f.two_over_w, -1.0f);
-    const float sy = fmaf(-fy, f.two_over_h, 1.0f);
-    float dx = fmaf(sy, f.Vy[0], fmaf(sx, f.Ux[0], f.Wd[0]));
-    float dy = fmaf(sy, f.Vy[1], fmaf(sx, f.Ux[1], f.Wd[1]));
-    float dz = fmaf(sy, f.Vy[2], fmaf(sx, f.Ux[2], f.Wd[2]));
+    const float sx = fmaf(fx, CF(f)->two_over_w, -1.0f);
+    const float sy = fmaf(-fy, CF(f)->two_over_h, 1.0f);
+    float dx = fmaf(sy, CF(f)->Vy[0], fmaf(sx, CF(f)->Ux[0], CF(f)->Wd[0]));
+    float dy = fmaf(sy, CF(f)->Vy[1], fmaf(sx, CF(f)->Ux[1], CF(f)->Wd[1]));
+    float dz = fmaf(sy, CF(f)->Vy[2], fmaf(sx, CF(f)->Ux[2], CF(f)->Wd[2]));
     const float inv_len = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
     dx = dx * inv_len; dy = dy * inv_len; dz = dz * inv_len;
 
     // float64 entry into the bounding sphere: the eye sits ~30 radii away, float32 would cost metres
     const double Dx = (double)dx, Dy = (double)dy, Dz = (double)dz;
     const double a = (Dx * Dx + Dy * Dy) + Dz * Dz;
-    const double b = (f.oc[0] * Dx + f.oc[1] * Dy) + f.oc[2] * Dz;
-    const double disc = b * b - a * f.cq;
+    const double b = (CF(f)->oc[0] * Dx + CF(f)->oc[1] * Dy) + CF(f)->oc[2] * Dz;
+    const double disc = b * b - a * CF(f)->cq;
     bool on_sphere = false;
     double t0 = 0.0, t1 = 0.0;
     if (disc > 0.0) {
@@ -396,13 +400,13 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     bool hit = false;
     float pa = 0.f, pb = 0.f, pc = 0.f, da = 0.f, db = 0.f, dc = 0.f, lo = 0.0f;
     if (on_sphere) {
-        const double pe0 = f.oc[0] + t0 * Dx, pe1 = f.oc[1] + t0 * Dy, pe2 = f.oc[2] + t0 * Dz;
-        pa = (float)((f.M[0][0] * pe0 + f.M[0][1] * pe1) + f.M[0][2] * pe2);
-        pb = (float)((f.M[1][0] * pe0 + f.M[1][1] * pe1) + f.M[1][2] * pe2);
-        pc = (float)((f.M[2][0] * pe0 + f.M[2][1] * pe1) + f.M[2][2] * pe2);
-        da = (float)((f.M[0][0] * Dx + f.M[0][1] * Dy) + f.M[0][2] * Dz);
-        db = (float)((f.M[1][0] * Dx + f.M[1][1] * Dy) + f.M[1][2] * Dz);
-        dc = (float)((f.M[2][0] * Dx + f.M[2][1] * Dy) + f.M[2][2] * Dz);
+        const double pe0 = CF(f)->oc[0] + t0 * Dx, pe1 = CF(f)->oc[1] + t0 * Dy, pe2 = CF(f)->oc[2] + t0 * Dz;
+        pa = (float)((CF(f)->M[0][0] * pe0 + CF(f)->M[0][1] * pe1) + CF(f)->M[0][2] * pe2);
+        pb = (float)((CF(f)->M[1][0] * pe0 + CF(f)->M[1][1] * pe1) + CF(f)->M[1][2] * pe2);
+        pc = (float)((CF(f)->M[2][0] * pe0 + CF(f)->M[2][1] * pe1) + CF(f)->M[2][2] * pe2);
+        da = (float)((CF(f)->M[0][0] * Dx + CF(f)->M[0][1] * Dy) + CF(f)->M[0][2] * Dz);
+        db = (float)((CF(f)->M[1][0] * Dx + CF(f)->M[1][1] * Dy) + CF(f)->M[1][2] * Dz);
+        dc = (float)((CF(f)->M[2][0] * Dx + CF(f)->M[2][1] * Dy) + CF(f)->M[2][2] * Dz);
         const float smax = (float)(t1 - t0);
         Seg sg;
         float hi = 0.0f;
@@ -423,30 +427,30 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     }
 
     if (!hit) {
-        if (f.sun_on) {  // D8
-            const float bq = fmaf(f.sc[2], dz, fmaf(f.sc[1], dy, f.sc[0] * dx));
-            const float dq = fmaf(bq, bq, -f.sun_cq);
+        if (CF(f)->sun_on) {  // D8
+            const float bq = fmaf(CF(f)->sc[2], dz, fmaf(CF(f)->sc[1], dy, CF(f)->sc[0] * dx));
+            const float dq = fmaf(bq, bq, -CF(f)->sun_cq);
             if (bq > 0.0f && dq > 0.0f) {
                 const float t = bq - sqrtf(dq);
-                o.c0 = o.c1 = o.c2 = f.sun_rad;
+                o.c0 = o.c1 = o.c2 = CF(f)->sun_rad;
                 o.hitflag = 1.0f;
-                o.h0 = fmaf(t, dx, f.eyef[0]);
-                o.h1 = fmaf(t, dy, f.eyef[1]);
-                o.h2 = fmaf(t, dz, f.eyef[2]);
+                o.h0 = fmaf(t, dx, CF(f)->eyef[0]);
+                o.h1 = fmaf(t, dy, CF(f)->eyef[1]);
+                o.h2 = fmaf(t, dz, CF(f)->eyef[2]);
                 o.h3 = t;
                 return;
             }
         }
-        if (f.bg) {  // D7
+        if (CF(f)->bg) {  // D7
             float el, az;
             latlon(dx, dy, dz, fmaf(dy, dy, dx * dx), el, az);
-            const float rowf = fmaf(el, f.bg_row_scale, f.bg_row_off);
-            const float colf = fmaf(az, f.bg_col_scale, f.bg_col_off);
+            const float rowf = fmaf(el, CF(f)->bg_row_scale, CF(f)->bg_row_off);
+            const float colf = fmaf(az, CF(f)->bg_col_scale, CF(f)->bg_col_off);
             int r = (int)floorf(rowf), c = (int)floorf(colf);
-            r = r < 0 ? 0 : (r > f.bg_h - 1 ? f.bg_h - 1 : r);
-            if (c >= f.bg_w) c -= f.bg_w;
+            r = r < 0 ? 0 : (r > CF(f)->bg_h - 1 ? CF(f)->bg_h - 1 : r);
+            if (c >= CF(f)->bg_w) c -= CF(f)->bg_w;
             if (c < 0) c = 0;
-            const uint32_t px = reinterpret_cast<const uint32_t*>(f.bg)[(int64_t)r * f.bg_w + c];
+            const uint32_t px = reinterpret_cast<const uint32_t*>(CF(f)->bg)[(int64_t)r * CF(f)->bg_w + c];
             o.c0 = (float)(px & 255u) * kInv255;
             o.c1 = (float)((px >> 8) & 255u) * kInv255;
             o.c2 = (float)((px >> 16) & 255u) * kInv255;
@@ -472,8 +476,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     const float de = dem_march<WIDE>(f, rowf, colf + 1.0f);
     const float dw = dem_march<WIDE>(f, rowf, colf - 1.0f);
     if (STATS) { cnt[ST_HEIGHT] += 4; cnt[ST_FETCH] += 4; }
-    const float dlat = (dn - ds) * f.dlat_scale;
-    const float dlon = (de - dw) * f.dlon_scale;
+    const float dlat = (dn - ds) * CF(f)->dlat_scale;
+    const float dlon = (de - dw) * CF(f)->dlon_scale;
     const float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
     const float inv_r = 1.0f / r, inv_rho = 1.0f / rhoc;
     const float sphi = hc * inv_r, cphi = rhoc * inv_r;
@@ -487,12 +491,15 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
     na = na * inv_nl; nb = nb * inv_nl; nc = nc * inv_nl;
 
     float al0, al1, al2;
-    if (f.color) {  // D4: bilinear RGBA8
-        const float rc = fmaf(lat, f.gc.row_scale, f.gc.row_off);
-        const float cc = fmaf(lon, f.gc.col_scale, f.gc.col_off);
-        const Tap t = grid_tap(f.gc, rc, cc);
-        const uint32_t* tex = reinterpret_cast<const uint32_t*>(f.color);
-        const int64_t ra = (int64_t)t.ra * f.gc.w, rb = (int64_t)t.rb * f.gc.w;
+    if (CF(f)->color) {  // D4: bilinear RGBA8
+        const float rc = fmaf(lat, CF(f)->gc.row_scale, CF(f)->gc.row_off);
+        const float cc = fmaf(lon, CF(f)->gc.col_scale, CF(f)->gc.col_off);
+        GridC gcl;   // scalar-load the colour grid constants (member-wise: no copy constructor across address spaces)
+        gcl.h = CF(f)->gc.h; gcl.w = CF(f)->gc.w; gcl.row_scale = CF(f)->gc.row_scale; gcl.row_off = CF(f)->gc.row_off;
+        gcl.col_scale = CF(f)->gc.col_scale; gcl.col_off = CF(f)->gc.col_off; gcl.wf = CF(f)->gc.wf;
+        const Tap t = grid_tap(gcl, rc, cc);
+        const uint32_t* tex = reinterpret_cast<const uint32_t*>(CF(f)->color);
+        const int64_t ra = (int64_t)t.ra * CF(f)->gc.w, rb = (int64_t)t.rb * CF(f)->gc.w;
         const uint32_t p00 = tex[ra + t.ca], p01 = tex[ra + t.cb], p10 = tex[rb + t.ca], p11 = tex[rb + t.cb];
         al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), t.fr, t.fc) * kInv255;
         al1 = lerp2((float)((p00 >> 8) & 255u), (float)((p01 >> 8) & 255u), (float)((p10 >> 8) & 255u),
@@ -501,23 +508,23 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
                     (float)((p11 >> 16) & 255u), t.fr, t.fc) * kInv255;
         if (STATS) cnt[ST_COLOUR]++;
     } else {
-        al0 = f.const_albedo[0]; al1 = f.const_albedo[1]; al2 = f.const_albedo[2];
+        al0 = CF(f)->const_albedo[0]; al1 = CF(f)->const_albedo[1]; al2 = CF(f)->const_albedo[2];
     }
 
     o.hitflag = 1.0f;
-    o.h0 = f.centerf[0] + fmaf(hc, f.Mf[2][0], fmaf(hb, f.Mf[1][0], ha * f.Mf[0][0]));
-    o.h1 = f.centerf[1] + fmaf(hc, f.Mf[2][1], fmaf(hb, f.Mf[1][1], ha * f.Mf[0][1]));
-    o.h2 = f.centerf[2] + fmaf(hc, f.Mf[2][2], fmaf(hb, f.Mf[1][2], ha * f.Mf[0][2]));
+    o.h0 = CF(f)->centerf[0] + fmaf(hc, CF(f)->Mf[2][0], fmaf(hb, CF(f)->Mf[1][0], ha * CF(f)->Mf[0][0]));
+    o.h1 = CF(f)->centerf[1] + fmaf(hc, CF(f)->Mf[2][1], fmaf(hb, CF(f)->Mf[1][1], ha * CF(f)->Mf[0][1]));
+    o.h2 = CF(f)->centerf[2] + fmaf(hc, CF(f)->Mf[2][2], fmaf(hb, CF(f)->Mf[1][2], ha * CF(f)->Mf[0][2]));
     o.h3 = (float)t0 + lo;
 
     // ---- D5: one sample of the spherical light, shadow ray marched through the same height field
-    const float eps = f.scene_eps;
+    const float eps = CF(f)->scene_eps;
     const float oa = fmaf(eps, na, ha), ob = fmaf(eps, nb, hb), oc = fmaf(eps, nc, hc);
-    const float ta = f.Lb[0] - oa, tb = f.Lb[1] - ob, tc = f.Lb[2] - oc;
+    const float ta = CF(f)->Lb[0] - oa, tb = CF(f)->Lb[1] - ob, tc = CF(f)->Lb[2] - oc;
     const float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
     const float inv_dist = 1.0f / sqrtf(d2);
     const float la = ta * inv_dist, lb = tb * inv_dist, lc = tc * inv_dist;
-    float sin2 = f.rL2 * (inv_dist * inv_dist);
+    float sin2 = CF(f)->rL2 * (inv_dist * inv_dist);
     if (sin2 > 1.0f) sin2 = 1.0f;
     const float cosmax = sqrtf(1.0f - sin2);
     const float omc = sin2 / (1.0f + cosmax);
@@ -544,7 +551,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         float sk_occ;
         if (march<WIDE, false, STATS>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return;
     }
-    const float wgt = (f.rad2 * omc) * cosi;
+    const float wgt = (CF(f)->rad2 * omc) * cosi;
     o.c0 = al0 * wgt; o.c1 = al1 * wgt; o.c2 = al2 * wgt;
 }
 
