@@ -38,11 +38,11 @@ class DeviceBuffer:
             raise MoonRTError(f"device download failed (code {rc})")
         return out
 
-    def upload(self, array):
+    def upload(self, array, offset=0):
         a = np.ascontiguousarray(array)
-        if a.nbytes > self.nbytes:
-            raise ValueError("upload larger than the buffer")
-        rc = self._lib.mrtx_dev_upload(self.device, self.ptr, a.ctypes.data, a.nbytes)
+        if offset < 0 or offset + a.nbytes > self.nbytes:
+            raise ValueError("upload outside the buffer")
+        rc = self._lib.mrtx_dev_upload(self.device, self.ptr + int(offset), a.ctypes.data, a.nbytes)
         if rc != 0:
             raise MoonRTError(f"device upload failed (code {rc})")
 

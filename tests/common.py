@@ -4,6 +4,7 @@ import numpy as np
 from oracle import orc
 from moonrtx_amd.renderer import MoonRT
 
+EXTRA_KEYS = ("dem_fetches", "mip_fetches", "kernel_ms")
 STAT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches",
              "background_fetches")
 
@@ -16,10 +17,10 @@ def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, ti
         rt.upload_background(bg)
         rt.apply_scene(scene)
         rt.set_params(flags=flags)
-        stats = {k: 0 for k in STAT_KEYS}
+        stats = {k: 0 for k in STAT_KEYS + EXTRA_KEYS}
         for nb in blocks:
             st = rt.render(nb)
-            for k in STAT_KEYS:
+            for k in STAT_KEYS + EXTRA_KEYS:
                 stats[k] += st[k]
         return rt.read_linear(), rt.read_hits(), stats, rt.read_rgba8()
     finally:
