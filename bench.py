@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--dem-scale", type=int, default=1, help="debug: shrink the DEM by this factor")
+    ap.add_argument("--path-seg", type=int, nargs=2, default=(1, 1), metavar=("MIN", "MAX"),
+                    help="path length in segments; (1,1) = direct light only (headline), the reference sets (2,4)")
     args = ap.parse_args()
 
     import torch
@@ -136,6 +138,7 @@ def main():
 
     scene = named_scene(args.scene, W, H, spp_per_launch=S)
     scene.max_spp = spp
+    scene.path_seg_min, scene.path_seg_max = args.path_seg
     rt = MoonRT(W, H, device=dev, rank=rank, world=world)
     rt.bind_dem(dem_buf, dem_h, dem_w)
     if col_buf is not None:
@@ -205,7 +208,8 @@ def main():
                                    + f", scene {args.scene}",
                        "parallelism": f"image tiles 32x32 round-robin over {world} GPU(s)"
                                       + (", RCCL gather of float4 radiance+hits to rank 0" if world > 1 else ""),
-                       "march": "step 5e-3, eps 3e-4, scene_epsilon 1e-4, 1 light sample + shadow ray per hit"},
+                       "march": "step 5e-3, eps 3e-4, scene_epsilon 1e-4, 1 light sample + shadow ray per path vertex, "
+                                f"path_seg_range {tuple(args.path_seg)}" + (" (direct light only)" if args.path_seg[1] <= 1 else "")},
             "kernel_ms": round(kernel_ms, 3),
             "frame_counts": frame,
             "bytes_per_ray": round(algorithmic_bytes(frame, W, H) / rays, 2),

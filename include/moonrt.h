@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRTX_ABI_VERSION 2
+#define MRTX_ABI_VERSION 3
 
 enum {
     MRTX_OK = 0,
@@ -56,7 +56,8 @@ typedef struct MrtxParams {
     float marching_step_eps;
     float tonemap_exposure;
     float tonemap_gamma;
-    uint32_t path_seg_min, path_seg_max;
+    uint32_t path_seg_min, path_seg_max;   /* path length in ray segments, camera segment = 1; max <= 1 traces direct
+                                              light only; beyond `min` the path survives Russian roulette            */
     uint32_t spp_per_launch;   /* samples per pixel per accumulation block: 1,2,4,...,64 */
     uint32_t max_spp;          /* max_accumulation_frames (informational for the ABI)   */
     uint32_t seed;
@@ -80,6 +81,7 @@ typedef struct MrtxStats {
     uint64_t dem_fetches;         /* DEM bilinear evaluations actually PERFORMED (steps the max-mip bound proves to
                                      be above the terrain are skipped; results are unchanged)                  */
     uint64_t mip_fetches;         /* max-mip texels read for those bounds (4 B each)                           */
+    uint64_t bounce_rays;         /* D6 path-continuation rays marched (0 when path_seg_max <= 1)              */
     double kernel_ms;             /* HIP-event time of the render kernel(s) of this call   */
     uint32_t launches;
     uint32_t reserved;

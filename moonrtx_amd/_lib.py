@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOONRT_LIB") or os.path.join(_HERE, "libmoonrt.so")   # MOONRT_LIB: A/B builds only
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MrtxConfig(C.Structure):
@@ -28,7 +28,7 @@ class MrtxParams(C.Structure):
 class MrtxStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("primary_hits", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("height_samples", C.c_uint64), ("colour_fetches", C.c_uint64),
-                ("background_fetches", C.c_uint64), ("dem_fetches", C.c_uint64), ("mip_fetches", C.c_uint64),
+                ("background_fetches", C.c_uint64), ("dem_fetches", C.c_uint64), ("mip_fetches", C.c_uint64), ("bounce_rays", C.c_uint64),
                 ("kernel_ms", C.c_double),
                 ("launches", C.c_uint32), ("reserved", C.c_uint32)]
 

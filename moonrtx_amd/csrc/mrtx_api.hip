@@ -16,7 +16,7 @@
 #include "../../include/moonrt.h"
 #include "mrtx_device.h"
 
-hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, hipStream_t st);
+hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, hipStream_t st);
 hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t npix, uint32_t ns, hipStream_t st);
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
                                      float invg, hipStream_t st);
@@ -179,6 +179,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
         k.bg_col_off = (float)(0.5 * (double)c->bg_w);
     }
     k.key0 = mix32h(c->prm.seed ^ 0x9E3779B9u);
+    k.path_seg_min = c->prm.path_seg_min; k.path_seg_max = c->prm.path_seg_max < 1 ? 1 : c->prm.path_seg_max;
     for (int i = 0; i < 3; i++) k.const_albedo[i] = c->prm.const_albedo[i];
     f.dem = c->dem; k.color = c->color; k.bg = c->bg;
     f.mip = c->mip; f.mip_pitch = c->mip_w + 2; f.mip_h = c->mip_h; f.mip_w = c->mip_w;
@@ -305,12 +306,12 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
     HIPCHK(c, hipMalloc((void**)&c->accum, fb));
     HIPCHK(c, hipMalloc((void**)&c->hits, fb));
     HIPCHK(c, hipMalloc(&c->scratch, fb));
-    HIPCHK(c, hipMalloc((void**)&c->stats_dev, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc((void**)&c->stats_dev, 16 * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc((void**)&c->cold_dev, sizeof(FrameCold)));
     HIPCHK(c, hipMalloc((void**)&c->tile_list_dev, (size_t)(c->n_local > 0 ? c->n_local : 1) * sizeof(int32_t)));
     HIPCHK(c, hipMemsetAsync(c->accum, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->hits, 0, fb, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 16 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MRTX_OK;
 }
@@ -521,9 +522,9 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
         culled_px = 0;
         c->tile_dirty.assign((size_t)c->n_local, 1);
     }
-    if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 8 * sizeof(unsigned long long), c->stream));
+    if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 16 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->stream));
+    HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->prm.path_seg_max > 1, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->blocks_done += (uint32_t)n_blocks;
@@ -534,12 +535,12 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
         out->kernel_ms = ms;
         out->launches = 1;
         if (stats) {
-            unsigned long long h[8];
+            unsigned long long h[16];
             HIPCHK(c, hipMemcpy(h, c->stats_dev, sizeof h, hipMemcpyDeviceToHost));
             out->primary_rays = h[0] + culled_px * (uint64_t)c->prm.spp_per_launch * (uint64_t)n_blocks;
             out->primary_hits = h[1]; out->shadow_rays = h[2];
             out->height_samples = h[3]; out->colour_fetches = h[4]; out->background_fetches = h[5];
-            out->dem_fetches = h[6]; out->mip_fetches = h[7];
+            out->dem_fetches = h[6]; out->mip_fetches = h[7]; out->bounce_rays = h[8];
         }
     }
     return MRTX_OK;

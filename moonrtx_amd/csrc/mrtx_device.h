@@ -34,6 +34,7 @@ struct FrameCold {
     int32_t bg_h, bg_w;
     float bg_row_scale, bg_row_off, bg_col_scale, bg_col_off;
     uint32_t key0;
+    uint32_t path_seg_min, path_seg_max;   // D6: path length in segments (camera segment = 1); max 1 = direct only
     float const_albedo[3];
     const uint8_t* color;   // RGBA8 or null
     const uint8_t* bg;      // RGBA8 or null
@@ -60,5 +61,5 @@ struct FrameC {
     uint32_t first_block, n_blocks;
     float* accum;           // W*H float4: running sums r,g,b,coverage
     float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block
-    unsigned long long* stats;  // 8 counters, see MrtxStats
+    unsigned long long* stats;  // 9 counters, see MrtxStats
 };

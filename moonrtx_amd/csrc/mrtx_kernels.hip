@@ -34,7 +34,7 @@ __device__ constexpr float kPi = 3.14159274101257324f;
 __device__ constexpr float kHalfPi = 1.57079637050628662f;
 __device__ constexpr float kInv255 = 0.003921568859368563f;
 
-enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_FETCH, ST_MIP, ST_N };
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_FETCH, ST_MIP, ST_BOUNCE, ST_N };
 
 // atan(q) ~= q * P(q^2) on [0,1], |err| <= 1.3e-7
 __device__ __forceinline__ float atan_poly(float q) {
@@ -355,12 +355,133 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
     return hit;
 }
 
+struct Vertex {
+    float pa, pb, pc;      // surface point (moon frame)
+    float na, nb, nc;      // unit normal
+    float al0, al1, al2;   // reflectance
+};
+
+// Duff et al., "Building an Orthonormal Basis, Revisited"
+__device__ __forceinline__ void duff_basis(float na, float nb, float nc, float& b1a, float& b1b, float& b1c, float& b2a,
+                                           float& b2b, float& b2c) {
+    const float sg = nc >= 0.0f ? 1.0f : -1.0f;
+    const float aa = -1.0f / (sg + nc);
+    const float bb = (na * nb) * aa;
+    b1a = fmaf(sg, (na * na) * aa, 1.0f); b1b = sg * bb; b1c = -sg * na;
+    b2a = bb; b2b = fmaf(nb * nb, aa, sg); b2c = -nb;
+}
+
+// D7: nearest environment texel along a scene-frame direction
+template <bool STATS>
+__device__ __forceinline__ void env_lookup(const FrameC& f, float dx, float dy, float dz, float& e0, float& e1, float& e2,
+                                           uint32_t* cnt) {
+    float el, az;
+    latlon(dx, dy, dz, fmaf(dy, dy, dx * dx), el, az);
+    const float rowf = fmaf(el, CF(f)->bg_row_scale, CF(f)->bg_row_off);
+    const float colf = fmaf(az, CF(f)->bg_col_scale, CF(f)->bg_col_off);
+    int r = (int)floorf(rowf), c = (int)floorf(colf);
+    r = r < 0 ? 0 : (r > CF(f)->bg_h - 1 ? CF(f)->bg_h - 1 : r);
+    if (c >= CF(f)->bg_w) c -= CF(f)->bg_w;
+    if (c < 0) c = 0;
+    const uint32_t px = reinterpret_cast<const uint32_t*>(CF(f)->bg)[(int64_t)r * CF(f)->bg_w + c];
+    e0 = (float)(px & 255u) * kInv255;
+    e1 = (float)((px >> 8) & 255u) * kInv255;
+    e2 = (float)((px >> 16) & 255u) * kInv255;
+    if (STATS) cnt[ST_BG]++;
+}
+
+// surface point -> normal (central differences of D one texel either side of it) and albedo (D4)
+template <bool STATS, bool WIDE>
+__device__ __forceinline__ void hit_vertex(const FrameC& f, float ha, float hb, float hc, Vertex& v, uint32_t* cnt) {
+    const float rho2 = fmaf(hb, hb, ha * ha);
+    const float r2 = fmaf(hc, hc, rho2);
+    const float rho = sqrtf(rho2);
+    const float r = sqrtf(r2);
+    float lat, lon;
+    latlon(ha, hb, hc, rho2, lat, lon);
+    const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
+    const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
+    // the two-texel border makes the +-1 texel taps plain two-load evaluations as well
+    const float dn = dem_march<WIDE>(f, rowf - 1.0f, colf);
+    const float ds = dem_march<WIDE>(f, rowf + 1.0f, colf);
+    const float de = dem_march<WIDE>(f, rowf, colf + 1.0f);
+    const float dw = dem_march<WIDE>(f, rowf, colf - 1.0f);
+    if (STATS) { cnt[ST_HEIGHT] += 4; cnt[ST_FETCH] += 4; }
+    const float dlat = (dn - ds) * CF(f)->dlat_scale;
+    const float dlon = (de - dw) * CF(f)->dlon_scale;
+    const float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
+    const float inv_r = 1.0f / r, inv_rho = 1.0f / rhoc;
+    const float sphi = hc * inv_r, cphi = rhoc * inv_r;
+    const float slam = ha * inv_rho, clam = hb * inv_rho;
+    const float glat = (f.Rf * inv_r) * dlat;
+    const float glon = (f.Rf * inv_rho) * dlon;
+    const float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
+    const float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
+    const float nc = fmaf(-glat, cphi, hc * inv_r);
+    const float inv_nl = 1.0f / sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
+    v.pa = ha; v.pb = hb; v.pc = hc;
+    v.na = na * inv_nl; v.nb = nb * inv_nl; v.nc = nc * inv_nl;
+    if (CF(f)->color) {  // D4: bilinear RGBA8
+        const float rc = fmaf(lat, CF(f)->gc.row_scale, CF(f)->gc.row_off);
+        const float cc = fmaf(lon, CF(f)->gc.col_scale, CF(f)->gc.col_off);
+        GridC gcl;   // scalar-load the colour grid constants (member-wise: no copy constructor across address spaces)
+        gcl.h = CF(f)->gc.h; gcl.w = CF(f)->gc.w; gcl.row_scale = CF(f)->gc.row_scale; gcl.row_off = CF(f)->gc.row_off;
+        gcl.col_scale = CF(f)->gc.col_scale; gcl.col_off = CF(f)->gc.col_off; gcl.wf = CF(f)->gc.wf;
+        const Tap t = grid_tap(gcl, rc, cc);
+        const uint32_t* tex = reinterpret_cast<const uint32_t*>(CF(f)->color);
+        const int64_t ra = (int64_t)t.ra * CF(f)->gc.w, rb = (int64_t)t.rb * CF(f)->gc.w;
+        const uint32_t p00 = tex[ra + t.ca], p01 = tex[ra + t.cb], p10 = tex[rb + t.ca], p11 = tex[rb + t.cb];
+        v.al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), t.fr, t.fc) * kInv255;
+        v.al1 = lerp2((float)((p00 >> 8) & 255u), (float)((p01 >> 8) & 255u), (float)((p10 >> 8) & 255u),
+                      (float)((p11 >> 8) & 255u), t.fr, t.fc) * kInv255;
+        v.al2 = lerp2((float)((p00 >> 16) & 255u), (float)((p01 >> 16) & 255u), (float)((p10 >> 16) & 255u),
+                      (float)((p11 >> 16) & 255u), t.fr, t.fc) * kInv255;
+        if (STATS) cnt[ST_COLOUR]++;
+    } else {
+        v.al0 = CF(f)->const_albedo[0]; v.al1 = CF(f)->const_albedo[1]; v.al2 = CF(f)->const_albedo[2];
+    }
+}
+
+// D5: one sample of the spherical light from a vertex, shadow ray marched through the same height field;
+// returns radiance * solid angle / pi * cos(theta_i) * visibility
+template <bool STATS, bool WIDE>
+__device__ __forceinline__ float direct_light(const FrameC& f, const Vertex& v, float u2, float u3, uint32_t* cnt) {
+    const float eps = CF(f)->scene_eps;
+    const float oa = fmaf(eps, v.na, v.pa), ob = fmaf(eps, v.nb, v.pb), oc = fmaf(eps, v.nc, v.pc);
+    const float ta = CF(f)->Lb[0] - oa, tb = CF(f)->Lb[1] - ob, tc = CF(f)->Lb[2] - oc;
+    const float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
+    const float inv_dist = 1.0f / sqrtf(d2);
+    const float la = ta * inv_dist, lb = tb * inv_dist, lc = tc * inv_dist;
+    float sin2 = CF(f)->rL2 * (inv_dist * inv_dist);
+    if (sin2 > 1.0f) sin2 = 1.0f;
+    const float cosmax = sqrtf(1.0f - sin2);
+    const float omc = sin2 / (1.0f + cosmax);
+    const float av = u2 * omc;
+    const float cost = 1.0f - av;
+    const float sint = sqrtf(av * (2.0f - av));
+    float cph, sph;
+    sincos_turn(u3, cph, sph);
+    float b1a, b1b, b1c, b2a, b2b, b2c;
+    duff_basis(la, lb, lc, b1a, b1b, b1c, b2a, b2b, b2c);
+    const float ca = sint * cph, sa = sint * sph;
+    const float wa = fmaf(cost, la, fmaf(sa, b2a, ca * b1a));
+    const float wb = fmaf(cost, lb, fmaf(sa, b2b, ca * b1b));
+    const float wc = fmaf(cost, lc, fmaf(sa, b2c, ca * b1c));
+    const float cosi = fmaf(v.nc, wc, fmaf(v.nb, wb, v.na * wa));
+    if (!(cosi > 0.0f)) return 0.0f;
+    if (STATS) cnt[ST_SHADOW]++;
+    Seg ssg;
+    float sk_occ;
+    if (march<WIDE, false, STATS>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return 0.0f;
+    return (CF(f)->rad2 * omc) * cosi;
+}
+
 struct SampleOut {
     float c0, c1, c2, hitflag;
     float h0, h1, h2, h3;
 };
 
-template <bool STATS, bool WIDE>
+template <bool STATS, bool WIDE, bool BOUNCE>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
@@ -441,118 +562,82 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
                 return;
             }
         }
-        if (CF(f)->bg) {  // D7
-            float el, az;
-            latlon(dx, dy, dz, fmaf(dy, dy, dx * dx), el, az);
-            const float rowf = fmaf(el, CF(f)->bg_row_scale, CF(f)->bg_row_off);
-            const float colf = fmaf(az, CF(f)->bg_col_scale, CF(f)->bg_col_off);
-            int r = (int)floorf(rowf), c = (int)floorf(colf);
-            r = r < 0 ? 0 : (r > CF(f)->bg_h - 1 ? CF(f)->bg_h - 1 : r);
-            if (c >= CF(f)->bg_w) c -= CF(f)->bg_w;
-            if (c < 0) c = 0;
-            const uint32_t px = reinterpret_cast<const uint32_t*>(CF(f)->bg)[(int64_t)r * CF(f)->bg_w + c];
-            o.c0 = (float)(px & 255u) * kInv255;
-            o.c1 = (float)((px >> 8) & 255u) * kInv255;
-            o.c2 = (float)((px >> 16) & 255u) * kInv255;
-            if (STATS) cnt[ST_BG]++;
-        }
+        if (CF(f)->bg) env_lookup<STATS>(f, dx, dy, dz, o.c0, o.c1, o.c2, cnt);  // D7
         return;
     }
 
-    // ---- hit point, normal from central differences of D, albedo
+    // ---- the path: vertex 1 is the primary hit; BOUNCE continues it (D6, set_uint("path_seg_range", min, max))
     if (STATS) cnt[ST_HITS]++;
-    const float ha = fmaf(lo, da, pa), hb = fmaf(lo, db, pb), hc = fmaf(lo, dc, pc);
-    const float rho2 = fmaf(hb, hb, ha * ha);
-    const float r2 = fmaf(hc, hc, rho2);
-    const float rho = sqrtf(rho2);
-    const float r = sqrtf(r2);
-    float lat, lon;
-    latlon(ha, hb, hc, rho2, lat, lon);
-    const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
-    const float colf = fmaf(lon, f.gd.col_scale, f.gd.col_off);
-    // the two-texel border makes the +-1 texel taps plain two-load evaluations as well
-    const float dn = dem_march<WIDE>(f, rowf - 1.0f, colf);
-    const float ds = dem_march<WIDE>(f, rowf + 1.0f, colf);
-    const float de = dem_march<WIDE>(f, rowf, colf + 1.0f);
-    const float dw = dem_march<WIDE>(f, rowf, colf - 1.0f);
-    if (STATS) { cnt[ST_HEIGHT] += 4; cnt[ST_FETCH] += 4; }
-    const float dlat = (dn - ds) * CF(f)->dlat_scale;
-    const float dlon = (de - dw) * CF(f)->dlon_scale;
-    const float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
-    const float inv_r = 1.0f / r, inv_rho = 1.0f / rhoc;
-    const float sphi = hc * inv_r, cphi = rhoc * inv_r;
-    const float slam = ha * inv_rho, clam = hb * inv_rho;
-    const float glat = (f.Rf * inv_r) * dlat;
-    const float glon = (f.Rf * inv_rho) * dlon;
-    float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
-    float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
-    float nc = fmaf(-glat, cphi, hc * inv_r);
-    const float inv_nl = 1.0f / sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
-    na = na * inv_nl; nb = nb * inv_nl; nc = nc * inv_nl;
-
-    float al0, al1, al2;
-    if (CF(f)->color) {  // D4: bilinear RGBA8
-        const float rc = fmaf(lat, CF(f)->gc.row_scale, CF(f)->gc.row_off);
-        const float cc = fmaf(lon, CF(f)->gc.col_scale, CF(f)->gc.col_off);
-        GridC gcl;   // scalar-load the colour grid constants (member-wise: no copy constructor across address spaces)
-        gcl.h = CF(f)->gc.h; gcl.w = CF(f)->gc.w; gcl.row_scale = CF(f)->gc.row_scale; gcl.row_off = CF(f)->gc.row_off;
-        gcl.col_scale = CF(f)->gc.col_scale; gcl.col_off = CF(f)->gc.col_off; gcl.wf = CF(f)->gc.wf;
-        const Tap t = grid_tap(gcl, rc, cc);
-        const uint32_t* tex = reinterpret_cast<const uint32_t*>(CF(f)->color);
-        const int64_t ra = (int64_t)t.ra * CF(f)->gc.w, rb = (int64_t)t.rb * CF(f)->gc.w;
-        const uint32_t p00 = tex[ra + t.ca], p01 = tex[ra + t.cb], p10 = tex[rb + t.ca], p11 = tex[rb + t.cb];
-        al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), t.fr, t.fc) * kInv255;
-        al1 = lerp2((float)((p00 >> 8) & 255u), (float)((p01 >> 8) & 255u), (float)((p10 >> 8) & 255u),
-                    (float)((p11 >> 8) & 255u), t.fr, t.fc) * kInv255;
-        al2 = lerp2((float)((p00 >> 16) & 255u), (float)((p01 >> 16) & 255u), (float)((p10 >> 16) & 255u),
-                    (float)((p11 >> 16) & 255u), t.fr, t.fc) * kInv255;
-        if (STATS) cnt[ST_COLOUR]++;
-    } else {
-        al0 = CF(f)->const_albedo[0]; al1 = CF(f)->const_albedo[1]; al2 = CF(f)->const_albedo[2];
-    }
-
+    Vertex v;
+    hit_vertex<STATS, WIDE>(f, fmaf(lo, da, pa), fmaf(lo, db, pb), fmaf(lo, dc, pc), v, cnt);
     o.hitflag = 1.0f;
-    o.h0 = CF(f)->centerf[0] + fmaf(hc, CF(f)->Mf[2][0], fmaf(hb, CF(f)->Mf[1][0], ha * CF(f)->Mf[0][0]));
-    o.h1 = CF(f)->centerf[1] + fmaf(hc, CF(f)->Mf[2][1], fmaf(hb, CF(f)->Mf[1][1], ha * CF(f)->Mf[0][1]));
-    o.h2 = CF(f)->centerf[2] + fmaf(hc, CF(f)->Mf[2][2], fmaf(hb, CF(f)->Mf[1][2], ha * CF(f)->Mf[0][2]));
+    o.h0 = CF(f)->centerf[0] + fmaf(v.pc, CF(f)->Mf[2][0], fmaf(v.pb, CF(f)->Mf[1][0], v.pa * CF(f)->Mf[0][0]));
+    o.h1 = CF(f)->centerf[1] + fmaf(v.pc, CF(f)->Mf[2][1], fmaf(v.pb, CF(f)->Mf[1][1], v.pa * CF(f)->Mf[0][1]));
+    o.h2 = CF(f)->centerf[2] + fmaf(v.pc, CF(f)->Mf[2][2], fmaf(v.pb, CF(f)->Mf[1][2], v.pa * CF(f)->Mf[0][2]));
     o.h3 = (float)t0 + lo;
 
-    // ---- D5: one sample of the spherical light, shadow ray marched through the same height field
-    const float eps = CF(f)->scene_eps;
-    const float oa = fmaf(eps, na, ha), ob = fmaf(eps, nb, hb), oc = fmaf(eps, nc, hc);
-    const float ta = CF(f)->Lb[0] - oa, tb = CF(f)->Lb[1] - ob, tc = CF(f)->Lb[2] - oc;
-    const float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
-    const float inv_dist = 1.0f / sqrtf(d2);
-    const float la = ta * inv_dist, lb = tb * inv_dist, lc = tc * inv_dist;
-    float sin2 = CF(f)->rL2 * (inv_dist * inv_dist);
-    if (sin2 > 1.0f) sin2 = 1.0f;
-    const float cosmax = sqrtf(1.0f - sin2);
-    const float omc = sin2 / (1.0f + cosmax);
-    const float av = u2 * omc;
-    const float cost = 1.0f - av;
-    const float sint = sqrtf(av * (2.0f - av));
-    float cph, sph;
-    sincos_turn(u3, cph, sph);
-    const float sg = lc >= 0.0f ? 1.0f : -1.0f;
-    const float aa = -1.0f / (sg + lc);
-    const float bb = (la * lb) * aa;
-    const float b1a = fmaf(sg, (la * la) * aa, 1.0f), b1b = sg * bb, b1c = -sg * la;
-    const float b2a = bb, b2b = fmaf(lb * lb, aa, sg), b2c = -lb;
-    const float ca = sint * cph, sa = sint * sph;
-    const float wa = fmaf(cost, la, fmaf(sa, b2a, ca * b1a));
-    const float wb = fmaf(cost, lb, fmaf(sa, b2b, ca * b1b));
-    const float wc = fmaf(cost, lc, fmaf(sa, b2c, ca * b1c));
-    const float cosi = fmaf(nc, wc, fmaf(nb, wb, na * wa));
-    if (!(cosi > 0.0f)) return;
-
-    if (STATS) cnt[ST_SHADOW]++;
-    {
-        Seg ssg;
-        float sk_occ;
-        if (march<WIDE, false, STATS>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return;
+    float t0r = 1.0f, t1r = 1.0f, t2r = 1.0f;   // path throughput
+    uint32_t seg = 1;
+    float ul1 = u2, ul2 = u3;
+    for (;;) {
+        const float wgt = direct_light<STATS, WIDE>(f, v, ul1, ul2, cnt);
+        o.c0 = fmaf(t0r * v.al0, wgt, o.c0);
+        o.c1 = fmaf(t1r * v.al1, wgt, o.c1);
+        o.c2 = fmaf(t2r * v.al2, wgt, o.c2);
+        if (!BOUNCE || seg >= CF(f)->path_seg_max) break;
+        // segment seg+1: cosine-weighted direction about the normal => throughput *= albedo
+        const uint32_t d0 = 4u + 5u * (seg - 1u);
+        t0r *= v.al0; t1r *= v.al1; t2r *= v.al2;
+        if (seg + 1u > CF(f)->path_seg_min) {   // Russian roulette beyond the guaranteed segments
+            float pcont = v.al0 > v.al1 ? v.al0 : v.al1;
+            pcont = pcont > v.al2 ? pcont : v.al2;
+            pcont = pcont > 1.0f ? 1.0f : pcont;
+            if (!(u01(ks, d0) < pcont)) break;
+            const float ip = 1.0f / pcont;
+            t0r *= ip; t1r *= ip; t2r *= ip;
+        }
+        const float uh1 = u01(ks, d0 + 1u), uh2 = u01(ks, d0 + 2u);
+        ul1 = u01(ks, d0 + 3u); ul2 = u01(ks, d0 + 4u);
+        const float rr = sqrtf(uh1), zz = sqrtf(1.0f - uh1);
+        float cph, sph;
+        sincos_turn(uh2, cph, sph);
+        float b1a, b1b, b1c, b2a, b2b, b2c;
+        duff_basis(v.na, v.nb, v.nc, b1a, b1b, b1c, b2a, b2b, b2c);
+        const float xx = rr * cph, yy = rr * sph;
+        const float eps = CF(f)->scene_eps;
+        const float boa = fmaf(eps, v.na, v.pa), bob = fmaf(eps, v.nb, v.pb), boc = fmaf(eps, v.nc, v.pc);
+        const float bda = fmaf(zz, v.na, fmaf(yy, b2a, xx * b1a));
+        const float bdb = fmaf(zz, v.nb, fmaf(yy, b2b, xx * b1b));
+        const float bdc = fmaf(zz, v.nc, fmaf(yy, b2c, xx * b1c));
+        if (STATS) cnt[ST_BOUNCE]++;
+        Seg bsg;
+        float bhi = 0.0f;
+        if (!march<WIDE, false, STATS>(f, boa, bob, boc, bda, bdb, bdc, 0.0f, bsg, bhi, cnt)) {
+            if (CF(f)->bg) {   // the path leaves the Moon: environment radiance along its direction (scene frame)
+                const float ex = fmaf(bdc, CF(f)->Mf[2][0], fmaf(bdb, CF(f)->Mf[1][0], bda * CF(f)->Mf[0][0]));
+                const float ey = fmaf(bdc, CF(f)->Mf[2][1], fmaf(bdb, CF(f)->Mf[1][1], bda * CF(f)->Mf[0][1]));
+                const float ez = fmaf(bdc, CF(f)->Mf[2][2], fmaf(bdb, CF(f)->Mf[1][2], bda * CF(f)->Mf[0][2]));
+                float e0, e1, e2;
+                env_lookup<STATS>(f, ex, ey, ez, e0, e1, e2, cnt);
+                o.c0 = fmaf(t0r, e0, o.c0);
+                o.c1 = fmaf(t1r, e1, o.c1);
+                o.c2 = fmaf(t2r, e2, o.c2);
+            }
+            break;
+        }
+        const int bk = (int)rintf(bhi * f.inv_step);
+        float blo = (float)(bk - 1) * f.step;
+        for (int i = 0; i < f.nbis; i++) {
+            const float mid = 0.5f * (blo + bhi);
+            const float ma = fmaf(mid, bda, boa), mb = fmaf(mid, bdb, bob), mc = fmaf(mid, bdc, boc);
+            const bool bel = below_seg<WIDE, true>(f, bsg, mid, ma, mb, mc, fmaf(mc, mc, fmaf(mb, mb, ma * ma)));
+            bhi = bel ? mid : bhi;
+            blo = bel ? blo : mid;
+        }
+        if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
+        hit_vertex<STATS, WIDE>(f, fmaf(blo, bda, boa), fmaf(blo, bdb, bob), fmaf(blo, bdc, boc), v, cnt);
+        seg++;
     }
-    const float wgt = (CF(f)->rad2 * omc) * cosi;
-    o.c0 = al0 * wgt; o.c1 = al1 * wgt; o.c2 = al2 * wgt;
 }
 
 template <int S>
@@ -567,7 +652,7 @@ __device__ __forceinline__ float tree_sum(float v) {
 #ifndef MRTX_MIN_WAVES
 #define MRTX_MIN_WAVES 5   // 94 VGPRs, 5 waves/SIMD, no spill: best of {4,5,6,8} measured (profiles/)
 #endif
-template <int S, bool STATS, bool WIDE>
+template <int S, bool STATS, bool WIDE, bool BOUNCE>
 __global__ void __launch_bounds__(256, MRTX_MIN_WAVES) render_kernel(const FrameC f) {
     constexpr int P = 64 / S;
     constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;
@@ -613,7 +698,7 @@ __global__ void __launch_bounds__(256, MRTX_MIN_WAVES) render_kernel(const Frame
         o.h0 = o.h1 = o.h2 = o.h3 = 0.f;
         for (uint32_t blk = 0; blk < f.n_blocks; blk++) {
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
-            if (inb) trace_sample<STATS, WIDE>(f, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            if (inb) trace_sample<STATS, WIDE, BOUNCE>(f, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
             s0 += tree_sum<S>(o.c0);
             s1 += tree_sum<S>(o.c1);
             s2 += tree_sum<S>(o.c2);
@@ -898,23 +983,26 @@ __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, in
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mrtx_api.hip)
 extern "C++" {
-hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, hipStream_t st) {
+hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, hipStream_t st) {
     const int subs = (f.tile_w >> 4) * (f.tile_h >> 4);
     const int groups = (f.n_active + 7) / 8;
     const dim3 grid((unsigned)(groups * subs * 8)), block(256);
     if (grid.x == 0) return hipSuccess;
     const bool wide = f.dem_wide != 0;
-#define MRTX_LAUNCH(SV, ST, WD) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD>), grid, block, 0, st, f)
+#define MRTX_LAUNCH(SV, ST, WD, BN) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, BN>), grid, block, 0, st, f)
+#define MRTX_CASE2(SV, BN)                                                                                 \
+        if (wide) { if (stats) MRTX_LAUNCH(SV, true, true, BN); else MRTX_LAUNCH(SV, false, true, BN); }   \
+        else { if (stats) MRTX_LAUNCH(SV, true, false, BN); else MRTX_LAUNCH(SV, false, false, BN); }
 #define MRTX_CASE(SV)                                                  \
     case SV:                                                           \
-        if (wide) { if (stats) MRTX_LAUNCH(SV, true, true); else MRTX_LAUNCH(SV, false, true); }   \
-        else { if (stats) MRTX_LAUNCH(SV, true, false); else MRTX_LAUNCH(SV, false, false); }      \
+        if (bounce) { MRTX_CASE2(SV, true) } else { MRTX_CASE2(SV, false) }   \
         break;
     switch (S) {
         MRTX_CASE(1) MRTX_CASE(2) MRTX_CASE(4) MRTX_CASE(8) MRTX_CASE(16) MRTX_CASE(32) MRTX_CASE(64)
         default: return hipErrorInvalidValue;
     }
 #undef MRTX_CASE
+#undef MRTX_CASE2
 #undef MRTX_LAUNCH
     return hipGetLastError();
 }

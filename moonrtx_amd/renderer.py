@@ -161,7 +161,8 @@ class MoonRT:
         self.set_params(scene_epsilon=s.scene_epsilon, marching_step=s.marching_step,
                         marching_step_eps=s.marching_step_eps, tonemap_exposure=s.exposure,
                         tonemap_gamma=s.gamma, spp_per_launch=s.spp_per_launch, max_spp=s.max_spp,
-                        seed=s.seed, const_albedo=s.const_albedo)
+                        seed=s.seed, const_albedo=s.const_albedo, path_seg_min=s.path_seg_min,
+                        path_seg_max=s.path_seg_max)
         self.set_camera(s.eye, s.target, s.up, s.vfov_deg)
         self.set_moon_frame(s.center, s.radius, s.u, s.v)
         self.set_light(s.light_pos, s.light_radius, s.light_radiance)

@@ -124,6 +124,9 @@ class SceneDesc:
     spp_per_launch: int = 64
     max_spp: int = ACCUMULATION_FRAMES
     seed: int = 1
+    # path length: 1 = direct light only (the headline workload); the reference sets (2, 4) -- moon_renderer.py:583
+    path_seg_min: int = 1
+    path_seg_max: int = 1
     const_albedo: Sequence[float] = (75.0 / 255.0,) * 3   # lut[128] at gamma 2.2 (data_loader.py:283-287)
     # camera (moon_renderer.py:513-520)
     eye: Sequence[float] = (0.0, -CAMERA_DISTANCE, 0.0)

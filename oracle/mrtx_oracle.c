@@ -41,6 +41,7 @@ typedef struct OrcScene {
     int32_t width, height;
     float scene_epsilon, marching_step, marching_step_eps;
     uint32_t spp_per_block, seed;
+    uint32_t path_seg_min, path_seg_max;   /* set_uint("path_seg_range", 2, 4), moon_renderer.py:583; max 1 = direct light only */
     float const_albedo[3];
     double eye[3], target[3], up[3], vfov_deg;
     double center[3], radius, u[3], v[3];
@@ -55,7 +56,7 @@ typedef struct OrcScene {
 } OrcScene;
 
 /* indices of the stats array */
-enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_N };
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_BOUNCE, ST_N };
 
 /* ------------------------------------------------------------------ spec constants */
 #define PI_D 3.14159265358979323846
@@ -396,6 +397,113 @@ static int march(const OrcScene* s, const Frame* f, const Ray* r, int primary, f
 }
 
 typedef struct Sample { float c[3]; float hitflag; float hit[4]; } Sample;
+typedef struct Vertex { float p[3], n[3], alb[3]; } Vertex;
+
+/* Duff et al., "Building an Orthonormal Basis, Revisited" */
+static inline void duff_basis(const float n[3], float b1[3], float b2[3]) {
+    float sg = n[2] >= 0.0f ? 1.0f : -1.0f;
+    float aa = -1.0f / (sg + n[2]);
+    float bb = (n[0] * n[1]) * aa;
+    b1[0] = fmaf(sg, (n[0] * n[0]) * aa, 1.0f); b1[1] = sg * bb; b1[2] = -sg * n[0];
+    b2[0] = bb; b2[1] = fmaf(n[1] * n[1], aa, sg); b2[2] = -n[1];
+}
+
+/* D7: nearest environment texel along a scene-frame direction */
+static inline void env_lookup(const OrcScene* s, const Frame* f, float dx, float dy, float dz, float out[3], uint64_t* st) {
+    float el, az;
+    orc_latlon(dx, dy, dz, &el, &az);
+    float rowf = fmaf(el, f->bg_row_scale, f->bg_row_off);
+    float colf = fmaf(az, f->bg_col_scale, f->bg_col_off);
+    int r = (int)floorf(rowf), c = (int)floorf(colf);
+    r = r < 0 ? 0 : (r > s->bg_h - 1 ? s->bg_h - 1 : r);
+    if (c >= s->bg_w) c -= s->bg_w;
+    if (c < 0) c = 0;
+    const uint8_t* px = s->bg + 4 * ((int64_t)r * s->bg_w + c);
+    out[0] = (float)px[0] * INV255;
+    out[1] = (float)px[1] * INV255;
+    out[2] = (float)px[2] * INV255;
+    st[ST_BG]++;
+}
+
+/* surface point -> normal (central differences of D one texel either side) and albedo (D4) */
+static void hit_vertex(const OrcScene* s, const Frame* f, float ha, float hb, float hc, Vertex* v, uint64_t* st) {
+    float rho2 = fmaf(hb, hb, ha * ha);
+    float r2 = fmaf(hc, hc, rho2);
+    float rho = sqrtf(rho2);
+    float r = sqrtf(r2);
+    float lat, lon;
+    orc_latlon(ha, hb, hc, &lat, &lon);
+    float rowf, colf;
+    grid_rc(&f->gd, lat, lon, &rowf, &colf);
+    float dn = dem_at(s->dem, &f->gd, rowf - 1.0f, colf);
+    float ds = dem_at(s->dem, &f->gd, rowf + 1.0f, colf);
+    float de = dem_at(s->dem, &f->gd, rowf, colf + 1.0f);
+    float dw = dem_at(s->dem, &f->gd, rowf, colf - 1.0f);
+    st[ST_HEIGHT] += 4;
+    float dlat = (dn - ds) * f->dlat_scale;
+    float dlon = (de - dw) * f->dlon_scale;
+    float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
+    float inv_r = 1.0f / r, inv_rho = 1.0f / rhoc;
+    float sphi = hc * inv_r, cphi = rhoc * inv_r;
+    float slam = ha * inv_rho, clam = hb * inv_rho;
+    float glat = (f->Rf * inv_r) * dlat;
+    float glon = (f->Rf * inv_rho) * dlon;
+    float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
+    float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
+    float nc = fmaf(-glat, cphi, hc * inv_r);
+    float inv_nl = 1.0f / sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
+    v->p[0] = ha; v->p[1] = hb; v->p[2] = hc;
+    v->n[0] = na * inv_nl; v->n[1] = nb * inv_nl; v->n[2] = nc * inv_nl;
+    if (s->color) {
+        float rc, cc; Tap t; int ch;
+        grid_rc(&f->gc, lat, lon, &rc, &cc);
+        grid_tap(&f->gc, rc, cc, &t);
+        for (ch = 0; ch < 3; ch++) {
+            float val = lerp2((float)s->color[4 * t.i00 + ch], (float)s->color[4 * t.i01 + ch],
+                              (float)s->color[4 * t.i10 + ch], (float)s->color[4 * t.i11 + ch], t.fr, t.fc);
+            v->alb[ch] = val * INV255;
+        }
+        st[ST_COLOUR]++;
+    } else {
+        v->alb[0] = s->const_albedo[0]; v->alb[1] = s->const_albedo[1]; v->alb[2] = s->const_albedo[2];
+    }
+}
+
+static int march(const OrcScene* s, const Frame* f, const Ray* r, int primary, float smax, Seg* sg, int* k_hit,
+                 uint64_t* st);
+
+/* D5: one sample of the spherical light from a vertex; returns radiance * solid angle / pi * cos * visibility */
+static float direct_light(const OrcScene* s, const Frame* f, const Vertex* v, float u2, float u3, uint64_t* st) {
+    float eps = s->scene_epsilon;
+    float oa = fmaf(eps, v->n[0], v->p[0]), ob = fmaf(eps, v->n[1], v->p[1]), occ = fmaf(eps, v->n[2], v->p[2]);
+    float ta = f->Lb[0] - oa, tb = f->Lb[1] - ob, tc = f->Lb[2] - occ;
+    float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
+    float inv_dist = 1.0f / sqrtf(d2);
+    float l[3] = { ta * inv_dist, tb * inv_dist, tc * inv_dist };
+    float sin2 = f->rL2 * (inv_dist * inv_dist);
+    if (sin2 > 1.0f) sin2 = 1.0f;
+    float cosmax = sqrtf(1.0f - sin2);
+    float omc = sin2 / (1.0f + cosmax);
+    float av = u2 * omc;
+    float cost = 1.0f - av;
+    float sint = sqrtf(av * (2.0f - av));
+    float cph, sph;
+    sincos_quadrant(u3, &cph, &sph);
+    float b1[3], b2[3];
+    duff_basis(l, b1, b2);
+    float ca = sint * cph, sa = sint * sph;
+    float wa = fmaf(cost, l[0], fmaf(sa, b2[0], ca * b1[0]));
+    float wb = fmaf(cost, l[1], fmaf(sa, b2[1], ca * b1[1]));
+    float wc = fmaf(cost, l[2], fmaf(sa, b2[2], ca * b1[2]));
+    float cosi = fmaf(v->n[2], wc, fmaf(v->n[1], wb, v->n[0] * wa));
+    if (!(cosi > 0.0f)) return 0.0f;
+    st[ST_SHADOW]++;
+    Ray sray = { oa, ob, occ, wa, wb, wc };
+    Seg ssg;
+    int kk = 0;
+    if (march(s, f, &sray, 0, 0.0f, &ssg, &kk, st)) return 0.0f;
+    return (f->rad2 * omc) * cosi;
+}
 
 static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32_t gs, Sample* o,
                          uint64_t* st) {
@@ -475,112 +583,79 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
                 return;
             }
         }
-        if (s->bg) {
-            float el, az;
-            orc_latlon(dx, dy, dz, &el, &az);
-            float rowf = fmaf(el, f->bg_row_scale, f->bg_row_off);
-            float colf = fmaf(az, f->bg_col_scale, f->bg_col_off);
-            int r = (int)floorf(rowf), c = (int)floorf(colf);
-            r = r < 0 ? 0 : (r > s->bg_h - 1 ? s->bg_h - 1 : r);
-            if (c >= s->bg_w) c -= s->bg_w;
-            if (c < 0) c = 0;
-            const uint8_t* px = s->bg + 4 * ((int64_t)r * s->bg_w + c);
-            o->c[0] = (float)px[0] * INV255;
-            o->c[1] = (float)px[1] * INV255;
-            o->c[2] = (float)px[2] * INV255;
-            st[ST_BG]++;
-        }
+        if (s->bg) env_lookup(s, f, dx, dy, dz, o->c, st);
         return;
     }
 
-    /* ---- hit: position, normal, albedo */
+    /* ---- the path: vertex 1 is the primary hit; D6 continues it (set_uint("path_seg_range", min, max)) */
     st[ST_HITS]++;
-    float ha = fmaf(lo, da, pa), hb = fmaf(lo, db, pb), hc = fmaf(lo, dc, pc);
-    float rho2 = fmaf(hb, hb, ha * ha);
-    float r2 = fmaf(hc, hc, rho2);
-    float rho = sqrtf(rho2);
-    float r = sqrtf(r2);
-    float lat, lon;
-    orc_latlon(ha, hb, hc, &lat, &lon);
-    float rowf, colf;
-    grid_rc(&f->gd, lat, lon, &rowf, &colf);
-    float dn = dem_at(s->dem, &f->gd, rowf - 1.0f, colf);
-    float ds = dem_at(s->dem, &f->gd, rowf + 1.0f, colf);
-    float de = dem_at(s->dem, &f->gd, rowf, colf + 1.0f);
-    float dw = dem_at(s->dem, &f->gd, rowf, colf - 1.0f);
-    st[ST_HEIGHT] += 4;
-    float dlat = (dn - ds) * f->dlat_scale;
-    float dlon = (de - dw) * f->dlon_scale;
-    float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
-    float inv_r = 1.0f / r, inv_rho = 1.0f / rhoc;
-    float sphi = hc * inv_r, cphi = rhoc * inv_r;
-    float slam = ha * inv_rho, clam = hb * inv_rho;
-    float glat = (f->Rf * inv_r) * dlat;
-    float glon = (f->Rf * inv_rho) * dlon;
-    float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
-    float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
-    float nc = fmaf(-glat, cphi, hc * inv_r);
-    float inv_nl = 1.0f / sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
-    na = na * inv_nl; nb = nb * inv_nl; nc = nc * inv_nl;
-
-    float alb[3];
-    if (s->color) {
-        float rc, cc; Tap t; int ch;
-        grid_rc(&f->gc, lat, lon, &rc, &cc);
-        grid_tap(&f->gc, rc, cc, &t);
-        for (ch = 0; ch < 3; ch++) {
-            float v = lerp2((float)s->color[4 * t.i00 + ch], (float)s->color[4 * t.i01 + ch],
-                            (float)s->color[4 * t.i10 + ch], (float)s->color[4 * t.i11 + ch], t.fr, t.fc);
-            alb[ch] = v * INV255;
-        }
-        st[ST_COLOUR]++;
-    } else {
-        alb[0] = s->const_albedo[0]; alb[1] = s->const_albedo[1]; alb[2] = s->const_albedo[2];
-    }
-
+    Vertex v;
+    hit_vertex(s, f, fmaf(lo, da, pa), fmaf(lo, db, pb), fmaf(lo, dc, pc), &v, st);
     o->hitflag = 1.0f;
-    o->hit[0] = f->centerf[0] + fmaf(hc, f->Mf[2][0], fmaf(hb, f->Mf[1][0], ha * f->Mf[0][0]));
-    o->hit[1] = f->centerf[1] + fmaf(hc, f->Mf[2][1], fmaf(hb, f->Mf[1][1], ha * f->Mf[0][1]));
-    o->hit[2] = f->centerf[2] + fmaf(hc, f->Mf[2][2], fmaf(hb, f->Mf[1][2], ha * f->Mf[0][2]));
+    o->hit[0] = f->centerf[0] + fmaf(v.p[2], f->Mf[2][0], fmaf(v.p[1], f->Mf[1][0], v.p[0] * f->Mf[0][0]));
+    o->hit[1] = f->centerf[1] + fmaf(v.p[2], f->Mf[2][1], fmaf(v.p[1], f->Mf[1][1], v.p[0] * f->Mf[0][1]));
+    o->hit[2] = f->centerf[2] + fmaf(v.p[2], f->Mf[2][2], fmaf(v.p[1], f->Mf[1][2], v.p[0] * f->Mf[0][2]));
     o->hit[3] = (float)t0 + lo;
 
-    /* ---- D5: one sample of the spherical light */
-    float eps = s->scene_epsilon;
-    float oa = fmaf(eps, na, ha), ob = fmaf(eps, nb, hb), occ = fmaf(eps, nc, hc);
-    float ta = f->Lb[0] - oa, tb = f->Lb[1] - ob, tc = f->Lb[2] - occ;
-    float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
-    float inv_dist = 1.0f / sqrtf(d2);
-    float la = ta * inv_dist, lb = tb * inv_dist, lc = tc * inv_dist;
-    float sin2 = f->rL2 * (inv_dist * inv_dist);
-    if (sin2 > 1.0f) sin2 = 1.0f;
-    float cosmax = sqrtf(1.0f - sin2);
-    float omc = sin2 / (1.0f + cosmax);
-    float av = u2 * omc;
-    float cost = 1.0f - av;
-    float sint = sqrtf(av * (2.0f - av));
-    float cph, sph;
-    sincos_quadrant(u3, &cph, &sph);
-    float sg = lc >= 0.0f ? 1.0f : -1.0f;
-    float aa = -1.0f / (sg + lc);
-    float bb = (la * lb) * aa;
-    float b1a = fmaf(sg, (la * la) * aa, 1.0f), b1b = sg * bb, b1c = -sg * la;
-    float b2a = bb, b2b = fmaf(lb * lb, aa, sg), b2c = -lb;
-    float ca = sint * cph, sa = sint * sph;
-    float wa = fmaf(cost, la, fmaf(sa, b2a, ca * b1a));
-    float wb = fmaf(cost, lb, fmaf(sa, b2b, ca * b1b));
-    float wc = fmaf(cost, lc, fmaf(sa, b2c, ca * b1c));
-    float cosi = fmaf(nc, wc, fmaf(nb, wb, na * wa));
-    if (!(cosi > 0.0f)) return;
-
-    st[ST_SHADOW]++;
-    {
-        Ray sray = { oa, ob, occ, wa, wb, wc };
-        Seg ssg;
-        int kk = 0;
-        if (march(s, f, &sray, 0, 0.0f, &ssg, &kk, st)) return;
+    float thr[3] = { 1.0f, 1.0f, 1.0f };
+    uint32_t seg = 1, max_seg = s->path_seg_max < 1 ? 1 : s->path_seg_max;
+    float ul1 = u2, ul2 = u3;
+    for (;;) {
+        float wgt = direct_light(s, f, &v, ul1, ul2, st);
+        o->c[0] = fmaf(thr[0] * v.alb[0], wgt, o->c[0]);
+        o->c[1] = fmaf(thr[1] * v.alb[1], wgt, o->c[1]);
+        o->c[2] = fmaf(thr[2] * v.alb[2], wgt, o->c[2]);
+        if (seg >= max_seg) break;
+        /* continue with segment seg+1: cosine-weighted direction about the normal => throughput *= albedo */
+        uint32_t d0 = 4u + 5u * (seg - 1u);
+        thr[0] *= v.alb[0]; thr[1] *= v.alb[1]; thr[2] *= v.alb[2];
+        if (seg + 1u > s->path_seg_min) {          /* Russian roulette beyond the guaranteed segments */
+            float pc_ = v.alb[0] > v.alb[1] ? v.alb[0] : v.alb[1];
+            pc_ = pc_ > v.alb[2] ? pc_ : v.alb[2];
+            pc_ = pc_ > 1.0f ? 1.0f : pc_;
+            if (!(u01(ks, d0) < pc_)) break;
+            float ip = 1.0f / pc_;
+            thr[0] *= ip; thr[1] *= ip; thr[2] *= ip;
+        }
+        float uh1 = u01(ks, d0 + 1u), uh2 = u01(ks, d0 + 2u);
+        ul1 = u01(ks, d0 + 3u); ul2 = u01(ks, d0 + 4u);
+        float rr = sqrtf(uh1), zz = sqrtf(1.0f - uh1), cph, sph;
+        sincos_quadrant(uh2, &cph, &sph);
+        float b1[3], b2[3];
+        duff_basis(v.n, b1, b2);
+        float xx = rr * cph, yy = rr * sph;
+        Ray br;
+        float eps = s->scene_epsilon;
+        br.oa = fmaf(eps, v.n[0], v.p[0]); br.ob = fmaf(eps, v.n[1], v.p[1]); br.oc = fmaf(eps, v.n[2], v.p[2]);
+        br.da = fmaf(zz, v.n[0], fmaf(yy, b2[0], xx * b1[0]));
+        br.db = fmaf(zz, v.n[1], fmaf(yy, b2[1], xx * b1[1]));
+        br.dc = fmaf(zz, v.n[2], fmaf(yy, b2[2], xx * b1[2]));
+        st[ST_BOUNCE]++;
+        Seg bsg;
+        int bk = 0;
+        if (!march(s, f, &br, 0, 0.0f, &bsg, &bk, st)) {
+            if (s->bg) {   /* the path leaves the Moon: environment radiance along its direction (scene frame) */
+                float ex = fmaf(br.dc, f->Mf[2][0], fmaf(br.db, f->Mf[1][0], br.da * f->Mf[0][0]));
+                float ey = fmaf(br.dc, f->Mf[2][1], fmaf(br.db, f->Mf[1][1], br.da * f->Mf[0][1]));
+                float ez = fmaf(br.dc, f->Mf[2][2], fmaf(br.db, f->Mf[1][2], br.da * f->Mf[0][2]));
+                float env[3];
+                env_lookup(s, f, ex, ey, ez, env, st);
+                o->c[0] = fmaf(thr[0], env[0], o->c[0]);
+                o->c[1] = fmaf(thr[1], env[1], o->c[1]);
+                o->c[2] = fmaf(thr[2], env[2], o->c[2]);
+            }
+            break;
+        }
+        float bhi = (float)bk * f->step, blo = (float)(bk - 1) * f->step;
+        int i;
+        for (i = 0; i < f->nbis; i++) {
+            float mid = 0.5f * (blo + bhi);
+            if (below_seg(s, f, &bsg, mid, fmaf(mid, br.da, br.oa), fmaf(mid, br.db, br.ob), fmaf(mid, br.dc, br.oc), st)) bhi = mid;
+            else blo = mid;
+        }
+        hit_vertex(s, f, fmaf(blo, br.da, br.oa), fmaf(blo, br.db, br.ob), fmaf(blo, br.dc, br.oc), &v, st);
+        seg++;
     }
-    float wgt = (f->rad2 * omc) * cosi;
-    o->c[0] = alb[0] * wgt; o->c[1] = alb[1] * wgt; o->c[2] = alb[2] * wgt;
 }
 
 /* Render n_blocks accumulation blocks of spp_per_block samples for pixels [x0,x1) x [y0,y1).

@@ -20,6 +20,7 @@ class OrcScene(C.Structure):
         ("width", C.c_int32), ("height", C.c_int32),
         ("scene_epsilon", C.c_float), ("marching_step", C.c_float), ("marching_step_eps", C.c_float),
         ("spp_per_block", C.c_uint32), ("seed", C.c_uint32),
+        ("path_seg_min", C.c_uint32), ("path_seg_max", C.c_uint32),
         ("const_albedo", C.c_float * 3),
         ("eye", C.c_double * 3), ("target", C.c_double * 3), ("up", C.c_double * 3), ("vfov_deg", C.c_double),
         ("center", C.c_double * 3), ("radius", C.c_double), ("u", C.c_double * 3), ("v", C.c_double * 3),
@@ -32,7 +33,7 @@ class OrcScene(C.Structure):
 
 
 STAT_NAMES = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches",
-              "background_fetches")
+              "background_fetches", "bounce_rays")
 
 _lib = None
 
@@ -137,6 +138,8 @@ class Oracle:
         s.marching_step_eps = scene.marching_step_eps
         s.spp_per_block = int(scene.spp_per_launch)
         s.seed = int(scene.seed)
+        s.path_seg_min = int(getattr(scene, "path_seg_min", 1))
+        s.path_seg_max = int(getattr(scene, "path_seg_max", 1))
         s.const_albedo = (C.c_float * 3)(*scene.const_albedo)
         for name in ("eye", "target", "up", "center", "u", "v", "light_pos", "sun_pos"):
             setattr(s, name, (C.c_double * 3)(*[float(t) for t in getattr(scene, name)]))
@@ -157,7 +160,7 @@ class Oracle:
         self.s = s
         self.accum = np.zeros((s.height, s.width, 4), np.float32)
         self.hits = np.zeros((s.height, s.width, 4), np.float32)
-        self.stats = np.zeros(6, np.uint64)
+        self.stats = np.zeros(len(STAT_NAMES), np.uint64)
         self.blocks_done = 0
 
     def reset(self):

@@ -69,3 +69,13 @@ def cone_dem(h, w, lat_deg, lon_deg, height_km, base_km):
     hk = np.clip(1.0 - dist_km / base_km, 0, None) * height_km
     e = (1.0 + hk / 1737.4).astype(np.float32)
     return e / e.max()
+
+
+def corrugated_dem(h, w, amplitude_km=3.0, wavelength_km=40.0):
+    """Egg-crate relief with steep (tens of degrees) slopes: surfaces see each other, so inter-reflection exists."""
+    lat = (0.5 - (np.arange(h) + 0.5) / h) * np.pi
+    lon = ((np.arange(w) + 0.5) / w - 0.5) * 2 * np.pi
+    k = 2 * np.pi * 1737.4 / wavelength_km
+    hk = amplitude_km * np.sin(k * lat)[:, None] * np.sin(k * lon)[None, :]
+    e = (1.0 + hk / 1737.4).astype(np.float32)
+    return e / e.max()

@@ -31,6 +31,7 @@ def test_facade_frame_equals_oracle(native_lib):
     lin = rt._rt.read_linear()
     hits = rt._rt.read_hits()
     s.vfov_deg = 4.2422
+    s.path_seg_min, s.path_seg_max = 2, 4          # what init_renderer sets (moon_renderer.py:583)
     lin_o, hits_o, _ = render_oracle(s, dem, col)
     assert_bit_equal(lin, lin_o, "facade frame vs oracle")
     assert_bit_equal(hits, hits_o, "facade hits vs oracle")

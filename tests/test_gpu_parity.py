@@ -137,6 +137,26 @@ def test_sky_tile_cull_is_result_preserving(native_lib, dem_small):
     assert out["cull"][0][..., :3].max() >= 2.0 - 1e-6      # the Sun disk is there (radiance 2.0)
 
 
+@pytest.mark.parametrize("seg", [(2, 2), (2, 4), (1, 3)])
+def test_multi_bounce_paths_match_oracle(native_lib, dem_small, seg):
+    """D6: path continuation with Russian roulette, next-event estimation at every vertex, environment on escape."""
+    col = synth_np.colour_map(90, 180)
+    rng = np.random.default_rng(11)
+    bg = rng.integers(0, 255, (32, 64, 4), dtype=np.uint8)
+    rough = synth_np.corrugated_dem(720, 1440)      # steep relief: bounce rays really do hit terrain again
+    s = named_scene("S1", 96, 72, spp_per_launch=16)
+    s.path_seg_min, s.path_seg_max = seg
+    _, st = check(s, rough, col, bg)
+    assert st["bounce_rays"] > 0 and st["shadow_rays"] > 0
+    if seg[0] >= 2:
+        assert st["bounce_rays"] >= st["primary_hits"]             # the first continuation is guaranteed
+        if seg[1] > 2:
+            assert st["bounce_rays"] > st["primary_hits"]          # some paths went on to a third segment
+    s2 = named_scene("S3", 64, 48, spp_per_launch=4)
+    s2.path_seg_min, s2.path_seg_max = seg
+    check(s2, dem_small, blocks=(2, 1))
+
+
 def test_wide_addressing_path_matches(native_lib, dem_small):
     """DEMs above 4 GiB (downscale 1: 17 GB) take 64-bit byte offsets; force that path on a small DEM."""
     from moonrtx_amd import _lib

@@ -129,3 +129,33 @@ def test_dem_ingest_matches_numpy_semantics(oracle_lib):
         mx = float(e.max()); e /= np.float32(mx)
         assert np.array_equal(got.view(np.uint32), e.view(np.uint32)), d
         assert np.float32(scale) == np.float32(mx) and got.max() == 1.0
+
+
+def test_multi_bounce_paths_behave_physically(oracle_lib):
+    """D6 (set_uint("path_seg_range", 2, 4), moon_renderer.py:580-583): inter-reflection only ADDS light, puts some
+    into directly-shadowed pixels, scales with albedo^2 (one more reflection), and is small next to the direct term."""
+    dem = synth_np.corrugated_dem(720, 1440)
+
+    def render(alb, seg):
+        s = sc.named_scene("S1", 72, 72, spp_per_launch=64)
+        s.const_albedo = (alb,) * 3
+        s.path_seg_min, s.path_seg_max = seg
+        o = orc.Oracle(s, dem)
+        st = o.render(1)
+        return o.linear()[..., :3].astype(np.float64), st
+
+    d1, st1 = render(0.3, (1, 1))
+    b1, stb = render(0.3, (2, 4))
+    assert st1["bounce_rays"] == 0 and stb["bounce_rays"] >= stb["primary_hits"] > 0
+    assert stb["bounce_rays"] <= 3 * stb["primary_hits"]              # at most 3 continuation segments per path
+    ind1 = b1 - d1
+    assert ind1.min() > -1e-6 and 0.0 < ind1.mean() < 0.25 * d1.mean()
+    assert (ind1[..., 0] > 0).sum() > 0.3 * (d1[..., 0] > 0).sum()      # inter-reflection is widespread on steep relief
+    d2, _ = render(0.6, (1, 1))
+    b2, _ = render(0.6, (2, 4))
+    assert abs(d2.mean() / d1.mean() - 2.0) < 1e-3                       # direct term is linear in albedo
+    ratio = (b2 - d2).mean() / ind1.mean()
+    assert 3.4 < ratio < 5.2, ratio                                      # ~ albedo^2 (+ higher orders)
+    # (2,2): exactly one continuation ray per primary hit, no roulette
+    _, st22 = render(0.3, (2, 2))
+    assert st22["bounce_rays"] == st22["primary_hits"]
