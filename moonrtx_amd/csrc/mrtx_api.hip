@@ -31,7 +31,7 @@ hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, h
 hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float* c, float* lat, float* lon, int n,
                                     hipStream_t st);
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st);
-hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, hipStream_t st);
+hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, int shift, hipStream_t st);
 hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out, hipStream_t st);
 
 struct mrtx_ctx {
@@ -44,7 +44,7 @@ struct mrtx_ctx {
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
     float* dem = nullptr; int dem_h = 0, dem_w = 0;   // padded (h+4) x (w+4) copy, always owned
-    float* mip = nullptr; int mip_h = 0, mip_w = 0;   // 64x64-texel max-mip of it (+ one-cell border)
+    float* mip = nullptr; int mip_h = 0, mip_w = 0, mip_shift = 0;   // max-mip of it, cell 2^mip_shift texels (+ one-cell border)
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
     unsigned long long* stats_dev = nullptr;
@@ -182,7 +182,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     k.path_seg_min = c->prm.path_seg_min; k.path_seg_max = c->prm.path_seg_max < 1 ? 1 : c->prm.path_seg_max;
     for (int i = 0; i < 3; i++) k.const_albedo[i] = c->prm.const_albedo[i];
     f.dem = c->dem; k.color = c->color; k.bg = c->bg;
-    f.mip = c->mip; f.mip_pitch = c->mip_w + 2; f.mip_h = c->mip_h; f.mip_w = c->mip_w;
+    f.mip = c->mip; f.mip_pitch = c->mip_w + 2; f.mip_h = c->mip_h; f.mip_w = c->mip_w; f.mip_shift = c->mip_shift;
     f.dem_pitch = c->dem_w + 4;
     f.dem_maxidx = (uint32_t)((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 4) + (uint64_t)(c->dem_w + 2));
     f.dem_wide = ((uint64_t)(c->dem_h + 4) * (uint64_t)(c->dem_w + 4) * 4ull > 0xFFFFFFFFull) ? 1 : 0;
@@ -346,14 +346,29 @@ static int ingest_dem(mrtx_ctx* c, const float* dev_src, int32_t h, int32_t w) {
     HIPCHK(c, hipMalloc((void**)&c->dem, bytes));
     HIPCHK(c, mrtx_launch_pad_dem(dev_src, c->dem, h, w, c->stream));
     if (c->mip) { HIPCHK(c, hipFree(c->mip)); }
-    c->mip = nullptr;
-    c->mip_h = (h + 63) / 64; c->mip_w = (w + 63) / 64;
-    HIPCHK(c, hipMalloc((void**)&c->mip, (size_t)(c->mip_h + 2) * (c->mip_w + 2) * sizeof(float)));
-    HIPCHK(c, mrtx_launch_mip(c->dem, h, w, c->mip, c->mip_h, c->mip_w, c->stream));
+    c->mip = nullptr; c->mip_shift = 0;   // (re)built by mrtx_render for the march step in force
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dem_h = h; c->dem_w = w;
     return MRTX_OK;
 }
+// The max-mip cell must cover a whole 16-step segment (plus tap margins) so that a segment's footprint touches at
+// most 2 x 2 cells: cell = 2^shift >= 16*step/texel + 3.5, clamped to [16, 1024] texels.
+static int ensure_mip(mrtx_ctx* c) {
+    const double texel = std::fmin(kPiD * c->radius / (double)c->dem_h, 2.0 * kPiD * c->radius / (double)c->dem_w);
+    const double span = 16.0 * (double)c->prm.marching_step / texel + 3.5;   // + the (-1, +2) tap margins of seg_setup
+    int shift = 4;
+    while ((1 << shift) < span && shift < 10) shift++;
+    if (c->mip && c->mip_shift == shift) return MRTX_OK;
+    if (c->mip) { HIPCHK(c, hipFree(c->mip)); }
+    c->mip = nullptr;
+    const int cell = 1 << shift;
+    c->mip_h = (c->dem_h + cell - 1) / cell; c->mip_w = (c->dem_w + cell - 1) / cell;
+    HIPCHK(c, hipMalloc((void**)&c->mip, (size_t)(c->mip_h + 2) * (c->mip_w + 2) * sizeof(float)));
+    HIPCHK(c, mrtx_launch_mip(c->dem, c->dem_h, c->dem_w, c->mip, c->mip_h, c->mip_w, shift, c->stream));
+    c->mip_shift = shift;
+    return MRTX_OK;
+}
+
 int mrtx_upload_dem(mrtx_ctx* c, const float* host, int32_t h, int32_t w) {
     if (!c) return MRTX_E_INVALID;
     if (!host || h < 2 || w < 2) return fail(c, MRTX_E_INVALID, "DEM must be a float32 (h>=2, w>=2) array");
@@ -474,6 +489,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     if (n_blocks < 1) return fail(c, MRTX_E_INVALID, "n_blocks must be >= 1");
     if (!c->dem) return fail(c, MRTX_E_STATE, "no displacement map: call mrtx_upload_dem first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (!(c->prm.flags & MRTX_F_NO_SKIP)) { const int rc_ = ensure_mip(c); if (rc_ != MRTX_OK) return rc_; }
     FrameC f;
     FrameCold cold;
     build_frame(c, f, cold);

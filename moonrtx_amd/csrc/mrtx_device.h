@@ -52,7 +52,7 @@ struct FrameC {
     int32_t dem_pitch, dem_wide;   // pitch = w+4 floats; wide = byte offsets need 64 bits (> 4 GiB)
     uint32_t dem_maxidx;           // (h+2)*pitch + (w+2): last padded index a 2x2 tap may start at
     const float* mip;       // max-mip, (mip_h+2) x (mip_w+2) incl. its border, or null (skipping disabled)
-    int32_t mip_pitch, mip_h, mip_w;
+    int32_t mip_pitch, mip_h, mip_w, mip_shift;   // cell = 2^mip_shift texels
     const FrameCold* cold;  // device memory
     // image-tile sharding (new) + accumulation state
     int32_t tile_w, tile_h, tiles_x, tiles_y, rank, world, n_local_tiles;

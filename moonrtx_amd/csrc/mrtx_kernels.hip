@@ -187,7 +187,6 @@ __device__ __forceinline__ Tap grid_tap(const GridC& g, float rowf, float colf) 
 // i.e. the float32 resolution of the coordinate itself).  Segments that touch the polar cap or straddle
 // the +/-180 seam evaluate every step exactly.  DEM evaluations, hit tests and counters are unchanged.
 constexpr int SEG_N = 16;
-constexpr int MIP_SHIFT = 6;   // max-mip cell = 64 x 64 texels
 struct Seg {
     float sa, ra, r1, r2, ca, c1, c2;
     int jlo, jhi;   // steps of this segment that can possibly be at/below the surface (see seg_setup)
@@ -232,10 +231,10 @@ __device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, f
 
     sg.jlo = 1; sg.jhi = SEG_N;
     if (f.mip != nullptr) {
-        const int i0 = ((int)floorf(fminf(rowA, fminf(rM, rowB))) - 1) >> MIP_SHIFT;
-        const int i1 = ((int)floorf(fmaxf(rowA, fmaxf(rM, rowB))) + 2) >> MIP_SHIFT;
-        const int j0 = ((int)floorf(fminf(colA, fminf(cM, colB))) - 1) >> MIP_SHIFT;
-        const int j1 = ((int)floorf(fmaxf(colA, fmaxf(cM, colB))) + 2) >> MIP_SHIFT;
+        const int i0 = ((int)floorf(fminf(rowA, fminf(rM, rowB))) - 1) >> f.mip_shift;
+        const int i1 = ((int)floorf(fmaxf(rowA, fmaxf(rM, rowB))) + 2) >> f.mip_shift;
+        const int j0 = ((int)floorf(fminf(colA, fminf(cM, colB))) - 1) >> f.mip_shift;
+        const int j1 = ((int)floorf(fmaxf(colA, fmaxf(cM, colB))) + 2) >> f.mip_shift;
         const bool usable = !sg.exact & (i1 - i0 <= 1) & (j1 - j0 <= 1) & (i0 >= -1) & (i1 <= f.mip_h) & (j0 >= -1) &
                             (j1 <= f.mip_w);
         if (usable) {
@@ -956,19 +955,20 @@ __global__ void probe_stream_kernel(const Pair* __restrict__ src, int64_t n_pair
     if (acc == 123456.789f) out[0] = acc;   // keep the loads alive
 }
 
-// max-mip of the padded DEM: cell (i, j) = max over texel rows [64i-2, 64i+65] (clamped) x columns [64j-2, 64j+65]
-// (wrapped) -- dilated by the two-texel border so that any bilinear tap whose indices land in a cell is covered.
-// Stored with a one-cell border of its own: (mh+2) x (mw+2), rows clamp, columns wrap.
+// max-mip of the padded DEM with cells of C = 2^shift texels: cell (i, j) = max over texel rows [C i-2, C i+C+1]
+// (clamped) x columns [C j-2, C j+C+1] (wrapped) -- dilated by the two-texel border so that any bilinear tap whose
+// indices land in a cell is covered.  Stored with a one-cell border of its own: (mh+2) x (mw+2), rows clamp,
+// columns wrap.  C is chosen on the host so that a 16-step segment spans at most two cells per axis.
 __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, int w, float* __restrict__ mip, int mh,
-                                 int mw) {
-    const int pitch = w + 4, mp = mw + 2;
+                                 int mw, int shift) {
+    const int pitch = w + 4, mp = mw + 2, C = 1 << shift;
     const int n = (mh + 2) * mp;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         int i = t / mp - 1, j = t % mp - 1;
         i = i < 0 ? 0 : (i > mh - 1 ? mh - 1 : i);
         j = j < 0 ? mw - 1 : (j > mw - 1 ? 0 : j);
-        const int r0 = max(64 * i - 2, -2), r1 = min(64 * i + 65, h + 1);
-        const int c0 = max(64 * j - 2, -2), c1 = min(64 * j + 65, w + 1);
+        const int r0 = max(C * i - 2, -2), r1 = min(C * i + C + 1, h + 1);
+        const int c0 = max(C * j - 2, -2), c1 = min(C * j + C + 1, w + 1);
         float m = 0.0f;
         for (int r = r0; r <= r1; r++) {
             const float* row = dem_padded + (int64_t)(r + 2) * pitch + 2;
@@ -1064,9 +1064,9 @@ hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out
     hipLaunchKernelGGL(mrtx::probe_stream_kernel, dim3(8192), dim3(256), 0, st, reinterpret_cast<const mrtx::Pair*>(src), n_pairs, out);
     return hipGetLastError();
 }
-hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, hipStream_t st) {
-    hipLaunchKernelGGL(mrtx::mip_build_kernel, dim3(grid_for((int64_t)(mh + 2) * (mw + 2))), dim3(256), 0, st, dem_padded,
-                       h, w, mip, mh, mw);
+hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, int shift, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::mip_build_kernel, dim3(grid_for((int64_t)(mh + 2) * (mw + 2))), dim3(64), 0, st, dem_padded,
+                       h, w, mip, mh, mw, shift);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st) {

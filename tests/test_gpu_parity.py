@@ -157,6 +157,38 @@ def test_multi_bounce_paths_match_oracle(native_lib, dem_small, seg):
     check(s2, dem_small, blocks=(2, 1))
 
 
+def test_edge_case_parameters_match_oracle(native_lib, dem_small):
+    """Degenerate but legal inputs: the spec must stay defined and both sides must agree."""
+    # 1x1 and sliver frames
+    for (w, h, spp) in ((1, 1, 64), (3, 1, 16), (1, 5, 4), (17, 3, 1)):
+        s = named_scene("S2", w, h, spp_per_launch=spp)
+        lin_h, hits_h, st_h, _ = render_hip(s, dem_small)
+        lin_o, hits_o, st_o = render_oracle(s, dem_small)
+        assert_bit_equal(lin_h, lin_o, f"{w}x{h} radiance"); assert_bit_equal(hits_h, hits_o, f"{w}x{h} hits")
+        assert {k: st_h[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
+    # no bisection (eps >= step), a huge step, no lift of the shadow origin
+    s = named_scene("S1", 64, 48, spp_per_launch=4); s.marching_step_eps = 1.0e-2
+    check(s, dem_small)
+    s = named_scene("S1", 64, 48, spp_per_launch=4); s.marching_step = 0.05; s.marching_step_eps = 2.0e-3
+    check(s, dem_small)
+    s = named_scene("S1", 64, 48, spp_per_launch=4); s.scene_epsilon = 0.0
+    check(s, dem_small)
+    # a point light (radius 0) still lights the surface; zero brightness renders black but hits are recorded
+    s = named_scene("S2", 48, 48, spp_per_launch=4); s.light_radius = 0.0
+    lin_h, hits_h, _, _ = render_hip(s, dem_small); lin_o, hits_o, _ = render_oracle(s, dem_small)
+    assert_bit_equal(lin_h, lin_o, "point light"); assert lin_o[..., :3].max() == 0.0      # zero solid angle, zero power
+    s = named_scene("S2", 48, 48, spp_per_launch=4); s.light_radiance = 0.0
+    lin_h, hits_h, _, _ = render_hip(s, dem_small); lin_o, hits_o, _ = render_oracle(s, dem_small)
+    assert_bit_equal(lin_h, lin_o, "dark"); assert_bit_equal(hits_h, hits_o, "dark hits"); assert (hits_o[..., 3] > 0).any()
+    # eye INSIDE the bounding sphere (between the sphere and the terrain), looking along the surface
+    s = named_scene("S2", 64, 48, spp_per_launch=4, libration=(0.0, 0.0))
+    s.eye = (0.0, -9.999, 0.0); s.target = (3.0, -9.6, 1.0); s.vfov_deg = 60.0
+    check(s, dem_small)
+    # a wide field of view with the Moon small in the frame, and a camera roll
+    s = named_scene("S1", 80, 60, spp_per_launch=4); s.vfov_deg = 40.0; s.up = (0.3, 0.0, 1.0)
+    check(s, dem_small)
+
+
 def test_wide_addressing_path_matches(native_lib, dem_small):
     """DEMs above 4 GiB (downscale 1: 17 GB) take 64-bit byte offsets; force that path on a small DEM."""
     from moonrtx_amd import _lib
