@@ -136,6 +136,11 @@ int mrtx_set_light(mrtx_ctx* ctx, const double pos[3], double radius, double rad
  * -- moon_renderer.py:647-650, :855.  radius <= 0 disables the disk. */
 int mrtx_set_sun_disk(mrtx_ctx* ctx, const double pos[3], double radius, double radiance);
 
+/* set_graph / update_graph / delete_geometry -- renderer_labels.py:295-300, :367-373, renderer_pins.py:54: ALL overlay
+ * graphs flattened into capsules, 12 floats each (ax ay az r  bx by bz 0  cr cg cb 0), scene coordinates, flat colour;
+ * they never shadow and are invisible to shadow / continuation rays (renderer_labels.py:132-139).  n = 0 removes them. */
+int mrtx_set_capsules(mrtx_ctx* ctx, const float* caps12, int32_t n);
+
 /* rt.refresh_scene() -- moon_renderer.py:488, :871: restart the accumulation cycle. */
 int mrtx_reset_accum(mrtx_ctx* ctx);
 

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mrtx_set_moon_frame": (C.c_int, [_VP, _D3, C.c_double, _D3, _D3]),
     "mrtx_set_light": (C.c_int, [_VP, _D3, C.c_double, C.c_double]),
     "mrtx_set_sun_disk": (C.c_int, [_VP, _D3, C.c_double, C.c_double]),
+    "mrtx_set_capsules": (C.c_int, [_VP, _VP, C.c_int32]),
     "mrtx_reset_accum": (C.c_int, [_VP]),
     "mrtx_render": (C.c_int, [_VP, C.c_int32, C.POINTER(MrtxStats)]),
     "mrtx_read_linear": (C.c_int, [_VP, _VP]),

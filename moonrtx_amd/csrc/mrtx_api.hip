@@ -16,7 +16,7 @@
 #include "../../include/moonrt.h"
 #include "mrtx_device.h"
 
-hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, hipStream_t st);
+hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, bool overlay, hipStream_t st);
 hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t npix, uint32_t ns, hipStream_t st);
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
                                      float invg, hipStream_t st);
@@ -49,6 +49,12 @@ struct mrtx_ctx {
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
     unsigned long long* stats_dev = nullptr;
     FrameCold* cold_dev = nullptr;
+    // D11 overlay capsules: host copy in scene coordinates; device copies relative to the Moon centre + tile bins
+    std::vector<float> caps_host;            // 12 floats per capsule
+    float* caps_dev = nullptr; int32_t* caps_off_dev = nullptr; int32_t* caps_idx_dev = nullptr;
+    size_t caps_dev_n = 0, caps_idx_cap = 0;
+    std::vector<int32_t> caps_off_host;      // per local tile, valid for caps_version
+    uint64_t caps_version = 0;               // scene_version the bins were built for
     int32_t* tile_list_dev = nullptr;   // n_local entries
     std::vector<int32_t> keep_uploaded;  // what tile_list_dev holds
     std::vector<int32_t> keep_cached;    // cull result for scene_version == cull_version
@@ -193,6 +199,76 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     f.tile_list = nullptr; f.n_active = c->n_local;
 }
 
+// D11: (re)build the device copy of the overlay capsules (relative to the Moon centre) and their per-tile bins.
+// A capsule is binned into every local tile its bounding sphere can project into (conservative: perspective
+// stretch factor 1 + tan^2, +2 px), so the kernel's nearest-hit search over a bin equals the search over all.
+int build_capsule_bins(mrtx_ctx* c) {
+    const size_t n = c->caps_host.size() / 12;
+    c->caps_off_host.assign((size_t)c->n_local + 1, 0);
+    if (n == 0) return MRTX_OK;
+    const int W = c->cfg.width, H = c->cfg.height;
+    double wv[3], uv[3], vv[3];
+    for (int i = 0; i < 3; i++) wv[i] = c->target[i] - c->eye[i];
+    unit3(wv);
+    cross(wv, c->up, uv); unit3(uv);
+    cross(uv, wv, vv);
+    const double th = std::tan(c->vfov * kPiD / 360.0), aspect = (double)W / (double)H;
+    std::vector<float> rel(n * 12);
+    std::vector<std::vector<int32_t>> bins((size_t)c->n_local);
+    for (size_t k = 0; k < n; k++) {
+        const float* p = &c->caps_host[12 * k];
+        float* q = &rel[12 * k];
+        for (int i = 0; i < 3; i++) {
+            q[i] = (float)((double)p[i] - c->center[i]);
+            q[4 + i] = (float)((double)p[4 + i] - c->center[i]);
+        }
+        q[3] = p[3]; q[7] = 0.0f; q[8] = p[8]; q[9] = p[9]; q[10] = p[10]; q[11] = 0.0f;
+        double m[3], half = 0.0;
+        for (int i = 0; i < 3; i++) { m[i] = 0.5 * ((double)p[i] + (double)p[4 + i]) - c->eye[i]; const double d = (double)p[4 + i] - (double)p[i]; half += d * d; }
+        const double rho = 0.5 * std::sqrt(half) + (double)p[3];
+        const double z = (m[0] * wv[0] + m[1] * wv[1]) + m[2] * wv[2];
+        if (z + rho <= 1.0e-9) continue;                       // entirely behind the eye
+        int tx0 = 0, tx1 = c->tiles_x - 1, ty0 = 0, ty1 = c->tiles_y - 1;
+        if (z - rho > 1.0e-6) {
+            const double x = (m[0] * uv[0] + m[1] * uv[1]) + m[2] * uv[2], y = (m[0] * vv[0] + m[1] * vv[1]) + m[2] * vv[2];
+            const double tx = x / z, ty = y / z;               // tangents of the view angles
+            const double px = (tx / (th * aspect) + 1.0) * 0.5 * W, py = (1.0 - ty / th) * 0.5 * H;
+            const double pr = rho / (z - rho) / th * (0.5 * H) * (1.0 + tx * tx + ty * ty) * 1.05 + 2.0;
+            const double fx0 = std::floor((px - pr) / c->cfg.tile_w), fx1 = std::floor((px + pr) / c->cfg.tile_w);
+            const double fy0 = std::floor((py - pr) / c->cfg.tile_h), fy1 = std::floor((py + pr) / c->cfg.tile_h);
+            if (fx1 < 0 || fy1 < 0 || fx0 > c->tiles_x - 1 || fy0 > c->tiles_y - 1) continue;
+            tx0 = (int)std::fmax(fx0, 0.0); tx1 = (int)std::fmin(fx1, (double)c->tiles_x - 1);
+            ty0 = (int)std::fmax(fy0, 0.0); ty1 = (int)std::fmin(fy1, (double)c->tiles_y - 1);
+        }
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const int t = ty * c->tiles_x + tx;
+                if (t % c->cfg.world == c->cfg.rank) bins[(size_t)(t / c->cfg.world)].push_back((int32_t)k);
+            }
+    }
+    std::vector<int32_t> idx;
+    for (int lt = 0; lt < c->n_local; lt++) {
+        c->caps_off_host[(size_t)lt] = (int32_t)idx.size();
+        idx.insert(idx.end(), bins[(size_t)lt].begin(), bins[(size_t)lt].end());
+    }
+    c->caps_off_host[(size_t)c->n_local] = (int32_t)idx.size();
+    if (c->caps_dev_n < n) {
+        if (c->caps_dev) { HIPCHK(c, hipFree(c->caps_dev)); c->caps_dev = nullptr; }
+        HIPCHK(c, hipMalloc((void**)&c->caps_dev, n * 12 * sizeof(float)));
+        c->caps_dev_n = n;
+    }
+    if (!c->caps_off_dev) HIPCHK(c, hipMalloc((void**)&c->caps_off_dev, ((size_t)c->n_local + 1) * sizeof(int32_t)));
+    if (c->caps_idx_cap < idx.size() + 1) {
+        if (c->caps_idx_dev) { HIPCHK(c, hipFree(c->caps_idx_dev)); c->caps_idx_dev = nullptr; }
+        c->caps_idx_cap = idx.size() * 2 + 64;
+        HIPCHK(c, hipMalloc((void**)&c->caps_idx_dev, c->caps_idx_cap * sizeof(int32_t)));
+    }
+    HIPCHK(c, hipMemcpy(c->caps_dev, rel.data(), n * 12 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->caps_off_dev, c->caps_off_host.data(), c->caps_off_host.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!idx.empty()) HIPCHK(c, hipMemcpy(c->caps_idx_dev, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return MRTX_OK;
+}
+
 // Host-side sky cull (exact): with no environment texture a pixel whose samples all miss the Moon's bounding
 // sphere and the Sun disk is identically zero (radiance, coverage and hit record).  A tile is kept unless the
 // cone of its view directions (tile-centre direction, half-angle = largest corner angle + 5 % + 1e-4 rad, pixel
@@ -247,6 +323,7 @@ void cull_tiles(const mrtx_ctx* c, std::vector<int32_t>& keep, uint64_t& culled_
             for (int k = 0; k < 2; k++)
                 if (cones[k].on && ang(d0, cones[k].ax) <= cones[k].half + gamma) need = true;
         }
+        if (!need && !c->caps_off_host.empty() && c->caps_off_host[(size_t)lt + 1] > c->caps_off_host[(size_t)lt]) need = true;   // overlay tubes here
         if (need) keep.push_back(lt);
         else culled_px += (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
     }
@@ -325,6 +402,9 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
     if (c->cold_dev) (void)hipFree(c->cold_dev);
+    if (c->caps_dev) (void)hipFree(c->caps_dev);
+    if (c->caps_off_dev) (void)hipFree(c->caps_off_dev);
+    if (c->caps_idx_dev) (void)hipFree(c->caps_idx_dev);
     if (c->tile_list_dev) (void)hipFree(c->tile_list_dev);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
@@ -478,6 +558,15 @@ int mrtx_set_sun_disk(mrtx_ctx* c, const double pos[3], double radius, double ra
     return MRTX_OK;
 }
 
+int mrtx_set_capsules(mrtx_ctx* c, const float* caps12, int32_t n) {
+    if (!c || n < 0 || (n > 0 && !caps12)) return MRTX_E_INVALID;
+    for (int64_t i = 0; i < (int64_t)n * 12; i++)
+        if (!std::isfinite(caps12[i])) return fail(c, MRTX_E_INVALID, "non-finite value in capsule %lld", (long long)(i / 12));
+    c->caps_host.assign(caps12, caps12 + (size_t)n * 12);
+    c->scene_version++;
+    return MRTX_OK;
+}
+
 int mrtx_reset_accum(mrtx_ctx* c) {
     if (!c) return MRTX_E_INVALID;
     c->blocks_done = 0;
@@ -490,10 +579,18 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     if (!c->dem) return fail(c, MRTX_E_STATE, "no displacement map: call mrtx_upload_dem first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (!(c->prm.flags & MRTX_F_NO_SKIP)) { const int rc_ = ensure_mip(c); if (rc_ != MRTX_OK) return rc_; }
+    if (c->caps_version != c->scene_version) {   // overlay bins follow the camera / moon frame / capsule list
+        const int rc_ = build_capsule_bins(c);
+        if (rc_ != MRTX_OK) return rc_;
+        c->caps_version = c->scene_version;
+        c->cull_version = 0;   // the sky cull depends on the bins
+    }
     FrameC f;
     FrameCold cold;
     build_frame(c, f, cold);
     f.cold = c->cold_dev;
+    cold.caps = c->caps_dev; cold.caps_off = c->caps_off_dev; cold.caps_idx = c->caps_idx_dev;
+    cold.n_caps = (int32_t)(c->caps_host.size() / 12);
     HIPCHK(c, hipMemcpyAsync(c->cold_dev, &cold, sizeof cold, hipMemcpyHostToDevice, c->stream));
     f.first_block = c->blocks_done;
     f.n_blocks = (uint32_t)n_blocks;
@@ -502,6 +599,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     if (c->prm.flags & MRTX_F_NO_SKIP) f.mip = nullptr;
     uint64_t culled_px = 0;
     if (c->tile_dirty.size() != (size_t)c->n_local) c->tile_dirty.assign((size_t)c->n_local, 0);
+    const bool overlay = !c->caps_host.empty();
     bool culling = false;
     if (!(c->prm.flags & MRTX_F_NO_CULL)) {
         if (c->cull_version != c->scene_version) {
@@ -540,7 +638,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     }
     if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 16 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->prm.path_seg_max > 1, c->stream));
+    HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->prm.path_seg_max > 1, overlay, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->blocks_done += (uint32_t)n_blocks;

@@ -38,6 +38,11 @@ struct FrameCold {
     float const_albedo[3];
     const uint8_t* color;   // RGBA8 or null
     const uint8_t* bg;      // RGBA8 or null
+    // D11 overlay tubes: 12 floats per capsule (a - centre, r, b - centre, 0, colour, 0) + per-local-tile CSR bins
+    const float* caps;
+    const int32_t* caps_off;   // n_local_tiles + 1
+    const int32_t* caps_idx;
+    int32_t n_caps;
 };
 
 struct FrameC {

@@ -475,13 +475,69 @@ __device__ __forceinline__ float direct_light(const FrameC& f, const Vertex& v, 
     return (CF(f)->rad2 * omc) * cosi;
 }
 
+// D11: nearest overlay capsule of this tile's bin along the primary ray.  ro = ray point closest to the Moon
+// centre (relative to the centre), d = unit direction; per capsule the origin is re-centred once more at the
+// capsule's first endpoint so the quadratic stays well-conditioned for radii ~1e-2 at a 300-unit eye distance.
+// The loop is wave-uniform (every lane walks the same bin), capsule data come through scalar loads.
+__device__ __forceinline__ float nearest_capsule(const FrameC& f, int lt, float r0, float r1, float r2v, float dx,
+                                                 float dy, float dz, int& which) {
+    typedef const __attribute__((address_space(4))) float* CFloat;
+    typedef const __attribute__((address_space(4))) int32_t* CInt;
+    const CInt off = (CInt)CF(f)->caps_off;
+    const CInt idx = (CInt)CF(f)->caps_idx;
+    const CFloat caps = (CFloat)CF(f)->caps;
+    float best = 1.0e30f;
+    which = -1;
+    const int i0 = off[lt], i1 = off[lt + 1];
+    for (int i = i0; i < i1; i++) {
+        const int k = idx[i];
+        const CFloat c = caps + 12 * k;
+        const float a0 = c[0], a1 = c[1], a2 = c[2], r = c[3];
+        const float e0 = a0 - r0, e1 = a1 - r1, e2 = a2 - r2v;
+        const float ta = fmaf(e2, dz, fmaf(e1, dy, e0 * dx));
+        const float o0 = fmaf(ta, dx, -e0), o1 = fmaf(ta, dy, -e1), o2 = fmaf(ta, dz, -e2);
+        const float ba0 = c[4] - a0, ba1 = c[5] - a1, ba2 = c[6] - a2;
+        const float baba = fmaf(ba2, ba2, fmaf(ba1, ba1, ba0 * ba0));
+        const float bard = fmaf(ba2, dz, fmaf(ba1, dy, ba0 * dx));
+        const float baoa = fmaf(ba2, o2, fmaf(ba1, o1, ba0 * o0));
+        const float rdoa = fmaf(dz, o2, fmaf(dy, o1, dx * o0));
+        const float oaoa = fmaf(o2, o2, fmaf(o1, o1, o0 * o0));
+        const float rr = r * r;
+        const float A = fmaf(-bard, bard, baba);
+        const float B = fmaf(baba, rdoa, -(baoa * bard));
+        const float C = fmaf(baba, oaoa, -(baoa * baoa)) - rr * baba;
+        const float h = fmaf(B, B, -(A * C));
+        float cand = -1.0f;
+        bool have = false;
+        float y = baoa;
+        if (A > 0.0f && h >= 0.0f) {
+            const float t = (-B - sqrtf(h)) / A;
+            y = fmaf(t, bard, baoa);
+            if (y > 0.0f && y < baba) { cand = t; have = true; }
+        }
+        if (!have) {   // rounded end nearest to where the axis test left the segment
+            const bool far_end = !(y <= 0.0f);
+            const float q0 = far_end ? o0 - ba0 : o0, q1 = far_end ? o1 - ba1 : o1, q2 = far_end ? o2 - ba2 : o2;
+            const float B2 = fmaf(dz, q2, fmaf(dy, q1, dx * q0));
+            const float C2 = fmaf(q2, q2, fmaf(q1, q1, q0 * q0)) - rr;
+            const float h2 = fmaf(B2, B2, -C2);
+            if (h2 > 0.0f) { cand = -B2 - sqrtf(h2); have = true; }
+        }
+        if (have) {
+            const float sc = ta + cand;
+            if (sc < best) { best = sc; which = k; }
+        }
+    }
+    return which >= 0 ? best : -1.0e30f;
+}
+
 struct SampleOut {
     float c0, c1, c2, hitflag;
     float h0, h1, h2, h3;
 };
 
-template <bool STATS, bool WIDE, bool BOUNCE>
-__device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint32_t gs, SampleOut& o,
+template <bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
+__device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
     const uint32_t kp = mix32(pix + CF(f)->key0);
@@ -517,9 +573,22 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         t1 = (-b + sq) * inva;
         if (t1 > 0.0) { on_sphere = true; if (t0 < 0.0) t0 = 0.0; }
     }
+    // D11: overlay tubes live outside the bounding sphere (r = 1.025 R, moon_grid.py:188): one wins the sample if it
+    // is hit in front of the sphere entry, or if the ray finds no terrain at all
+    int cap = -1;
+    float cap_s = 0.0f, cr0 = 0.0f, cr1 = 0.0f, cr2 = 0.0f;
+    double tc0 = 0.0;
+    bool cap_front = false;
+    if (OVERLAY) {
+        tc0 = -b * (double)(1.0f / (float)a);
+        cr0 = (float)(CF(f)->oc[0] + tc0 * Dx); cr1 = (float)(CF(f)->oc[1] + tc0 * Dy); cr2 = (float)(CF(f)->oc[2] + tc0 * Dz);
+        cap_s = nearest_capsule(f, lt, cr0, cr1, cr2, dx, dy, dz, cap);
+        if (cap >= 0 && !(cap_s > (float)(-tc0))) cap = -1;   // behind the eye
+        cap_front = cap >= 0 && (!on_sphere || cap_s < (float)(t0 - tc0));
+    }
     bool hit = false;
     float pa = 0.f, pb = 0.f, pc = 0.f, da = 0.f, db = 0.f, dc = 0.f, lo = 0.0f;
-    if (on_sphere) {
+    if (on_sphere && !cap_front) {
         const double pe0 = CF(f)->oc[0] + t0 * Dx, pe1 = CF(f)->oc[1] + t0 * Dy, pe2 = CF(f)->oc[2] + t0 * Dz;
         pa = (float)((CF(f)->M[0][0] * pe0 + CF(f)->M[0][1] * pe1) + CF(f)->M[0][2] * pe2);
         pb = (float)((CF(f)->M[1][0] * pe0 + CF(f)->M[1][1] * pe1) + CF(f)->M[1][2] * pe2);
@@ -546,6 +615,17 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int x, int y, uint
         }
     }
 
+    if (OVERLAY && !hit && cap >= 0) {
+        typedef const __attribute__((address_space(4))) float* CFloat;
+        const CFloat c = (CFloat)CF(f)->caps + 12 * cap;
+        o.c0 = c[8]; o.c1 = c[9]; o.c2 = c[10];
+        o.hitflag = 1.0f;
+        o.h0 = CF(f)->centerf[0] + fmaf(cap_s, dx, cr0);
+        o.h1 = CF(f)->centerf[1] + fmaf(cap_s, dy, cr1);
+        o.h2 = CF(f)->centerf[2] + fmaf(cap_s, dz, cr2);
+        o.h3 = (float)tc0 + cap_s;
+        return;
+    }
     if (!hit) {
         if (CF(f)->sun_on) {  // D8
             const float bq = fmaf(CF(f)->sc[2], dz, fmaf(CF(f)->sc[1], dy, CF(f)->sc[0] * dx));
@@ -651,7 +731,7 @@ __device__ __forceinline__ float tree_sum(float v) {
 #ifndef MRTX_MIN_WAVES
 #define MRTX_MIN_WAVES 5   // 94 VGPRs, 5 waves/SIMD, no spill: best of {4,5,6,8} measured (profiles/)
 #endif
-template <int S, bool STATS, bool WIDE, bool BOUNCE>
+template <int S, bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
 __global__ void __launch_bounds__(256, MRTX_MIN_WAVES) render_kernel(const FrameC f) {
     constexpr int P = 64 / S;
     constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;
@@ -697,7 +777,7 @@ __global__ void __launch_bounds__(256, MRTX_MIN_WAVES) render_kernel(const Frame
         o.h0 = o.h1 = o.h2 = o.h3 = 0.f;
         for (uint32_t blk = 0; blk < f.n_blocks; blk++) {
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
-            if (inb) trace_sample<STATS, WIDE, BOUNCE>(f, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            if (inb) trace_sample<STATS, WIDE, BOUNCE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
             s0 += tree_sum<S>(o.c0);
             s1 += tree_sum<S>(o.c1);
             s2 += tree_sum<S>(o.c2);
@@ -983,16 +1063,17 @@ __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, in
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mrtx_api.hip)
 extern "C++" {
-hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, hipStream_t st) {
+hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, bool overlay, hipStream_t st) {
     const int subs = (f.tile_w >> 4) * (f.tile_h >> 4);
     const int groups = (f.n_active + 7) / 8;
     const dim3 grid((unsigned)(groups * subs * 8)), block(256);
     if (grid.x == 0) return hipSuccess;
     const bool wide = f.dem_wide != 0;
-#define MRTX_LAUNCH(SV, ST, WD, BN) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, BN>), grid, block, 0, st, f)
-#define MRTX_CASE2(SV, BN)                                                                                 \
-        if (wide) { if (stats) MRTX_LAUNCH(SV, true, true, BN); else MRTX_LAUNCH(SV, false, true, BN); }   \
-        else { if (stats) MRTX_LAUNCH(SV, true, false, BN); else MRTX_LAUNCH(SV, false, false, BN); }
+#define MRTX_LAUNCH(SV, ST, WD, BN, OV) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, BN, OV>), grid, block, 0, st, f)
+#define MRTX_CASE3(SV, BN, OV)                                                                                     \
+        if (wide) { if (stats) MRTX_LAUNCH(SV, true, true, BN, OV); else MRTX_LAUNCH(SV, false, true, BN, OV); }   \
+        else { if (stats) MRTX_LAUNCH(SV, true, false, BN, OV); else MRTX_LAUNCH(SV, false, false, BN, OV); }
+#define MRTX_CASE2(SV, BN) if (overlay) { MRTX_CASE3(SV, BN, true) } else { MRTX_CASE3(SV, BN, false) }
 #define MRTX_CASE(SV)                                                  \
     case SV:                                                           \
         if (bounce) { MRTX_CASE2(SV, true) } else { MRTX_CASE2(SV, false) }   \
@@ -1003,6 +1084,7 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, h
     }
 #undef MRTX_CASE
 #undef MRTX_CASE2
+#undef MRTX_CASE3
 #undef MRTX_LAUNCH
     return hipGetLastError();
 }

@@ -156,6 +156,14 @@ class MoonRT:
         self._check(self._lib.mrtx_set_sun_disk(self._ctx, vec3(pos), float(radius), float(radiance)),
                     "mrtx_set_sun_disk")
 
+    def set_capsules(self, capsules):
+        """Overlay tubes: (n, 12) float32 (see moonrtx_amd.overlays.graph_to_capsules); None / empty removes them."""
+        if capsules is None or len(capsules) == 0:
+            self._check(self._lib.mrtx_set_capsules(self._ctx, None, 0), "mrtx_set_capsules")
+            return
+        a = np.ascontiguousarray(capsules, np.float32).reshape(-1, 12)
+        self._check(self._lib.mrtx_set_capsules(self._ctx, a.ctypes.data, a.shape[0]), "mrtx_set_capsules")
+
     def apply_scene(self, s):
         """Push a moonrtx_amd.scene.SceneDesc (everything except textures)."""
         self.set_params(scene_epsilon=s.scene_epsilon, marching_step=s.marching_step,

@@ -15,8 +15,7 @@ What differs, by design: there is no Tk window here (no Tk on a headless GPU nod
 are None and the `_gui_*` handler slots are plain attributes a viewer may call.  One launch adds
 `spp_per_launch` samples per pixel (a whole 64-lane wavefront per pixel) instead of one:
 max_accumulation_frames=64 is ONE launch, max_accumulation_frames=1 (the interactive preview,
-moon_renderer.py:457-488) is a 1-spp launch.  Overlay graph geometry (set_graph) and the NVENC encoder
-are accepted / refused explicitly: they are outside this round's scope.
+moon_renderer.py:457-488) is a 1-spp launch.  The NVENC encoder is refused explicitly (no AMD analogue here).
 """
 import threading
 import warnings
@@ -247,17 +246,39 @@ class TkOptiX:
         self._wake.notify_all()
 
     def set_graph(self, name, pos=None, edges=None, r=None, c=None, mat=None, **_k):
-        """Overlay tubes (renderer_labels.py:295-300, renderer_pins.py:54): stored, not yet rendered."""
-        self._graphs[name] = {"pos": np.asarray(pos), "edges": np.asarray(edges), "r": r, "c": c, "mat": mat}
-        self._warn_once("graph", "overlay graph geometry is stored but not rendered by this backend yet")
+        """set_graph(name, pos=, edges=, r=, c=, mat=) -- overlay tubes (renderer_labels.py:295-300, :367-373,
+        renderer_pins.py:54): flat colour, never shadowing (renderer_labels.py:132-139)."""
+        with self._padlock:
+            self._graphs[name] = {"pos": np.asarray(pos, float), "edges": np.asarray(edges), "r": r, "c": c, "mat": mat}
+            self._push_graphs()
 
     def update_graph(self, name, pos=None, r=None, c=None, **_k):
-        if name in self._graphs and pos is not None:
-            self._graphs[name]["pos"] = np.asarray(pos)
+        """update_graph(name, pos=, r=) -- renderer_labels.py:209, :231-234, :324-325 (r=0 hides)."""
+        with self._padlock:
+            g = self._graphs.get(name)
+            if g is None:
+                return
+            if pos is not None:
+                g["pos"] = np.asarray(pos, float)
+            if r is not None:
+                g["r"] = r
+            if c is not None:
+                g["c"] = c
+            self._push_graphs()
+
+    def _push_graphs(self):
+        from .overlays import graph_to_capsules
+        parts = [graph_to_capsules(g["pos"], g["edges"], g["r"] if g["r"] is not None else 0.01,
+                                   g["c"] if g["c"] is not None else 0.8) for g in self._graphs.values()]
+        caps = np.concatenate(parts) if parts else np.zeros((0, 12), np.float32)
+        self._rt.set_capsules(caps)
+        self._dirty = True
+        self._wake.notify_all()
 
     def delete_geometry(self, name):
-        self._graphs.pop(name, None)
         with self._padlock:
+            if self._graphs.pop(name, None) is not None:
+                self._push_graphs()
             if self._geoms.pop(name, None) is not None and name == self._sun_name:
                 self._rt.set_sun_disk((0, 0, 0), 0.0, 0.0)
                 self._sun_name = None

@@ -53,6 +53,10 @@ typedef struct OrcScene {
     int32_t color_h, color_w;
     const uint8_t* bg;
     int32_t bg_h, bg_w;
+    /* D11 overlay tubes (set_graph, renderer_labels.py:295-300): n_caps x 12 floats, scene coordinates:
+     * ax ay az r  bx by bz 0  cr cg cb 0 -- flat colour, never shadow, invisible to shadow / continuation rays */
+    const float* caps;
+    int32_t n_caps;
 } OrcScene;
 
 /* indices of the stats array */
@@ -505,6 +509,58 @@ static float direct_light(const OrcScene* s, const Frame* f, const Vertex* v, fl
     return (f->rad2 * omc) * cosi;
 }
 
+/* Nearest overlay capsule along the primary ray.  ro = ray point closest to the Moon centre (relative to the
+ * centre), d = unit direction; per capsule the origin is re-centred once more at the capsule's first endpoint
+ * (ta = (a - ro).d, oa = (ro - a) + ta d) so that the quadratic stays well-conditioned for radii ~1e-2 at a
+ * 300-unit eye distance.  Returns the parameter relative to `ro` (or -1e30) and the index of the capsule. */
+static float nearest_capsule(const OrcScene* s, const Frame* f, const float ro[3], float dx, float dy, float dz, int* which) {
+    float best = 1.0e30f;
+    int k;
+    *which = -1;
+    for (k = 0; k < s->n_caps; k++) {
+        const float* c = s->caps + 12 * k;
+        float a0 = (float)((double)c[0] - s->center[0]), a1 = (float)((double)c[1] - s->center[1]), a2 = (float)((double)c[2] - s->center[2]);
+        float b0 = (float)((double)c[4] - s->center[0]), b1 = (float)((double)c[5] - s->center[1]), b2 = (float)((double)c[6] - s->center[2]);
+        float r = c[3];
+        float e0 = a0 - ro[0], e1 = a1 - ro[1], e2 = a2 - ro[2];
+        float ta = fmaf(e2, dz, fmaf(e1, dy, e0 * dx));
+        float o0 = fmaf(ta, dx, -e0), o1 = fmaf(ta, dy, -e1), o2 = fmaf(ta, dz, -e2);
+        float ba0 = b0 - a0, ba1 = b1 - a1, ba2 = b2 - a2;
+        float baba = fmaf(ba2, ba2, fmaf(ba1, ba1, ba0 * ba0));
+        float bard = fmaf(ba2, dz, fmaf(ba1, dy, ba0 * dx));
+        float baoa = fmaf(ba2, o2, fmaf(ba1, o1, ba0 * o0));
+        float rdoa = fmaf(dz, o2, fmaf(dy, o1, dx * o0));
+        float oaoa = fmaf(o2, o2, fmaf(o1, o1, o0 * o0));
+        float r2 = r * r;
+        float A = fmaf(-bard, bard, baba);
+        float B = fmaf(baba, rdoa, -(baoa * bard));
+        float C = fmaf(baba, oaoa, -(baoa * baoa)) - r2 * baba;
+        float h = fmaf(B, B, -(A * C));
+        float cand = -1.0f;
+        int have = 0;
+        float y = baoa;
+        if (A > 0.0f && h >= 0.0f) {
+            float t = (-B - sqrtf(h)) / A;
+            y = fmaf(t, bard, baoa);
+            if (y > 0.0f && y < baba) { cand = t; have = 1; }
+        }
+        if (!have) {   /* rounded end nearest to where the axis test left the segment */
+            float q0 = o0, q1 = o1, q2 = o2;
+            if (!(y <= 0.0f)) { q0 = o0 - ba0; q1 = o1 - ba1; q2 = o2 - ba2; }
+            float B2 = fmaf(dz, q2, fmaf(dy, q1, dx * q0));
+            float C2 = fmaf(q2, q2, fmaf(q1, q1, q0 * q0)) - r2;
+            float h2 = fmaf(B2, B2, -C2);
+            if (h2 > 0.0f) { cand = -B2 - sqrtf(h2); have = 1; }
+        }
+        if (have) {
+            float sc = ta + cand;
+            if (sc < best) { best = sc; *which = k; }
+        }
+    }
+    (void)f;
+    return *which >= 0 ? best : -1.0e30f;
+}
+
 static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32_t gs, Sample* o,
                          uint64_t* st) {
     uint32_t pix = (uint32_t)y * (uint32_t)s->width + (uint32_t)x;
@@ -540,9 +596,21 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
         t1 = (-b + sq) * inva;
         if (t1 > 0.0) { on_sphere = 1; if (t0 < 0.0) t0 = 0.0; }
     }
+    /* D11: overlay tubes live outside the bounding sphere (r = 1.025 R, moon_grid.py:188): one wins the sample if
+     * it is hit in front of the sphere entry, or if the ray finds no terrain at all */
+    int cap = -1;
+    float cap_s = 0.0f, cro[3] = { 0.0f, 0.0f, 0.0f };
+    double tc0 = 0.0;
+    if (s->n_caps > 0) {
+        tc0 = -b * (double)(1.0f / (float)a);   /* closest approach to the Moon centre (float32 reciprocal: a ~ 1) */
+        cro[0] = (float)(f->oc[0] + tc0 * Dx); cro[1] = (float)(f->oc[1] + tc0 * Dy); cro[2] = (float)(f->oc[2] + tc0 * Dz);
+        cap_s = nearest_capsule(s, f, cro, dx, dy, dz, &cap);
+        if (cap >= 0 && !(cap_s > (float)(-tc0))) cap = -1;            /* behind the eye */
+    }
+    int cap_front = cap >= 0 && (!on_sphere || cap_s < (float)(t0 - tc0));
     int hit = 0;
     float pa = 0, pb = 0, pc = 0, da = 0, db = 0, dc = 0, lo = 0.0f;
-    if (on_sphere) {
+    if (on_sphere && !cap_front) {
         double pe0 = f->oc[0] + t0 * Dx, pe1 = f->oc[1] + t0 * Dy, pe2 = f->oc[2] + t0 * Dz;
         pa = (float)((f->M[0][0] * pe0 + f->M[0][1] * pe1) + f->M[0][2] * pe2);
         pb = (float)((f->M[1][0] * pe0 + f->M[1][1] * pe1) + f->M[1][2] * pe2);
@@ -567,6 +635,16 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
         }
     }
 
+    if (!hit && cap >= 0) {
+        const float* c = s->caps + 12 * cap;
+        o->c[0] = c[8]; o->c[1] = c[9]; o->c[2] = c[10];
+        o->hitflag = 1.0f;
+        o->hit[0] = f->centerf[0] + fmaf(cap_s, dx, cro[0]);
+        o->hit[1] = f->centerf[1] + fmaf(cap_s, dy, cro[1]);
+        o->hit[2] = f->centerf[2] + fmaf(cap_s, dz, cro[2]);
+        o->hit[3] = (float)tc0 + cap_s;
+        return;
+    }
     if (!hit) {
         /* D8 Sun disk, then D7 environment */
         if (f->sun_on) {

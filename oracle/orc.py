@@ -29,6 +29,7 @@ class OrcScene(C.Structure):
         ("dem", C.c_void_p), ("dem_h", C.c_int32), ("dem_w", C.c_int32),
         ("color", C.c_void_p), ("color_h", C.c_int32), ("color_w", C.c_int32),
         ("bg", C.c_void_p), ("bg_h", C.c_int32), ("bg_w", C.c_int32),
+        ("caps", C.c_void_p), ("n_caps", C.c_int32),
     ]
 
 
@@ -125,7 +126,7 @@ def dem_from_ldem(src_i16, downscale):
 class Oracle:
     """Stateful wrapper that mirrors the product's create/upload/set/render/read sequence."""
 
-    def __init__(self, scene, dem, color=None, bg=None):
+    def __init__(self, scene, dem, color=None, bg=None, capsules=None):
         """`scene` is any object with the attribute names of moonrtx_amd.scene.SceneDesc."""
         self.L = lib()
         self.dem = np.ascontiguousarray(dem, np.float32)
@@ -157,6 +158,11 @@ class Oracle:
         if self.bg is not None:
             s.bg = self.bg.ctypes.data
             s.bg_h, s.bg_w = self.bg.shape[:2]
+        self.caps = None
+        if capsules is not None and len(capsules):
+            self.caps = np.ascontiguousarray(capsules, np.float32).reshape(-1, 12)
+            s.caps = self.caps.ctypes.data
+            s.n_caps = self.caps.shape[0]
         self.s = s
         self.accum = np.zeros((s.height, s.width, 4), np.float32)
         self.hits = np.zeros((s.height, s.width, 4), np.float32)

@@ -9,13 +9,14 @@ STAT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "c
              "background_fetches", "bounce_rays")
 
 
-def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, tile=(32, 32), flags=1):
+def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, tile=(32, 32), flags=1, capsules=None):
     rt = MoonRT(scene.width, scene.height, rank=rank, world=world, tile=tile)
     try:
         rt.upload_dem(dem)
         rt.upload_color(color)
         rt.upload_background(bg)
         rt.apply_scene(scene)
+        rt.set_capsules(capsules)
         rt.set_params(flags=flags)
         stats = {k: 0 for k in STAT_KEYS + EXTRA_KEYS}
         for nb in blocks:
@@ -27,8 +28,8 @@ def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, ti
         rt.close()
 
 
-def render_oracle(scene, dem, color=None, bg=None, blocks=(1,), region=None):
-    o = orc.Oracle(scene, dem, color, bg)
+def render_oracle(scene, dem, color=None, bg=None, blocks=(1,), region=None, capsules=None):
+    o = orc.Oracle(scene, dem, color, bg, capsules)
     for nb in blocks:
         st = o.render(nb, region)
     return o.linear(), o.hits.copy(), st

@@ -168,8 +168,20 @@ def test_render_thread_callbacks_and_padlock_contract():
 
 def test_unsupported_pieces_are_explicit():
     rt, be, _ = make()
-    with pytest.warns(UserWarning):
-        rt.set_graph("grid", pos=np.zeros((2, 3)), edges=np.zeros((1, 2), np.int32), r=0.01, c=1.0)
+    # overlay graphs (renderer_labels.py:295-300, :324-325, :367-373): flattened into capsules; radius 0 hides
+    pos = np.array([[0, -10.25, 0], [1, -10.2, 0], [1, -10.2, 1], [5, 5, 5]], float)
+    rt.set_graph("grid", pos=pos, edges=np.array([[0, 1], [1, 2]], np.int32), r=0.006, c=[0.5, 0.5, 0.5], mat="grid_material")
+    caps = be.last("set_capsules")[1][0]
+    assert caps.shape == (2, 12) and np.allclose(caps[0, :4], [0, -10.25, 0, 0.006]) and np.allclose(caps[1, 8:11], 0.5)
+    rt.set_graph("labels", pos=pos, edges=np.array([[0, 1], [2, 3]], np.int32), r=np.array([0.008, 0.008, 0.0, 0.0], np.float32),
+                 c=[1.0, 0.9, 0.3], mat="spot_label_material")
+    assert be.last("set_capsules")[1][0].shape == (3, 12)            # the zero-radius edge is dropped
+    rt.update_graph("grid", r=0.0)                                   # hide (show_moon_grid(False))
+    assert be.last("set_capsules")[1][0].shape == (1, 12)
+    rt.update_graph("grid", pos=pos * 2.0, r=0.006)
+    assert np.allclose(be.last("set_capsules")[1][0][0, :3], [0, -20.5, 0])
+    rt.delete_geometry("labels"); rt.delete_geometry("grid")
+    assert len(be.last("set_capsules")[1][0]) == 0
     with pytest.raises(NotImplementedError):
         rt.encoder_create(fps=30, bitrate=8)
     assert rt.encoder_is_open() is False

@@ -189,6 +189,51 @@ def test_edge_case_parameters_match_oracle(native_lib, dem_small):
     check(s, dem_small)
 
 
+def test_overlay_tubes_match_oracle(native_lib, dem_small):
+    """D11 (set_graph): flat, non-shadowing tubes outside the bounding sphere; binned per tile on the host, so the
+    nearest hit over a tile's bin must equal the oracle's search over every capsule."""
+    from moonrtx_amd import overlays, _lib
+    from moonrtx_amd.renderer import MoonRT
+    s = named_scene("S1", 200, 150, spp_per_launch=8)
+    pos, edges, r, c = overlays.graticule(rotation=s.rotation, tube=0.02)
+    caps = overlays.graph_to_capsules(pos, edges, r, c)
+    # a "label" graph with per-vertex radii (night-side labels hidden by zero radii, renderer_labels.py:126-128)
+    lp = np.array([[2.0, -10.3, 1.0], [2.6, -10.25, 1.0], [2.6, -10.25, 1.5], [-12.0, 0.0, 3.0], [-12.5, 0.0, 3.5]])
+    caps = np.concatenate([caps, overlays.graph_to_capsules(lp, [[0, 1], [1, 2], [3, 4]], np.array([0.03, 0.03, 0.03, 0.0, 0.0]),
+                                                            [1.0, 0.9, 0.3])])
+    lin_h, hits_h, st_h, _ = render_hip(s, dem_small, capsules=caps, tile=(16, 16))
+    lin_o, hits_o, st_o = render_oracle(s, dem_small, capsules=caps)
+    assert_bit_equal(lin_h, lin_o, "overlay radiance"); assert_bit_equal(hits_h, hits_o, "overlay hits")
+    assert {k: st_h[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
+    base, _, st_b, _ = render_hip(s, dem_small)
+    touched = (lin_h != base).any(-1)
+    assert touched.sum() > 1500 and st_h["primary_hits"] < st_b["primary_hits"]    # tubes hide some terrain samples
+    night = (base[..., 3] > 0.99) & (base[..., 0] == 0.0)                           # night-side pixels: tubes still show
+    assert (lin_h[night][:, 0] > 0).sum() > 50
+    yellow = (lin_h[..., 0] - lin_h[..., 2]) - (base[..., 0] - base[..., 2])        # the label is (1, 0.9, 0.3)
+    assert yellow.max() > 0.05
+    # zoomed view + sharding + removal
+    s2 = named_scene("S2", 96, 64, spp_per_launch=4); s2.vfov_deg = 0.8; s2.target = (2.3, 0.0, 1.2)
+    for world in (1, 2):
+        rts = []
+        for rk in range(world):
+            rt = MoonRT(s2.width, s2.height, rank=rk, world=world, tile=(16, 16))
+            rt.upload_dem(dem_small); rt.apply_scene(s2); rt.set_capsules(caps); rt.render(1)
+            rts.append(rt)
+        if world == 2:
+            from moonrtx_amd.renderer import DeviceBuffer
+            buf = DeviceBuffer(rts[1].shard_bytes()); rts[1].pack_shard(buf.ptr); rts[0].unpack_shard(1, buf.ptr)
+        lin2 = rts[0].read_linear()
+        lin2_o, _, _ = render_oracle(s2, dem_small, capsules=caps)
+        assert_bit_equal(lin2, lin2_o, f"zoomed overlay, world={world}")
+        if world == 1:
+            rts[0].set_capsules(None); rts[0].reset(); rts[0].render(1)
+            plain, _, _ = render_oracle(s2, dem_small)
+            assert_bit_equal(rts[0].read_linear(), plain, "overlay removed")
+        for rt in rts:
+            rt.close()
+
+
 def test_wide_addressing_path_matches(native_lib, dem_small):
     """DEMs above 4 GiB (downscale 1: 17 GB) take 64-bit byte offsets; force that path on a small DEM."""
     from moonrtx_amd import _lib
