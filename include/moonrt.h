@@ -113,6 +113,11 @@ int mrtx_bind_color_device(mrtx_ctx* ctx, const void* dev_rgba8, int32_t h, int3
  * renderer's linear space (the facade applies the gamma of set_background on the host). */
 int mrtx_upload_background(mrtx_ctx* ctx, const uint8_t* rgba, int32_t h, int32_t w);
 
+/* add_postproc("Overlay") + set_texture_2d("frame_overlay", rgba, filter_mode="Nearest") -- renderer_video.py:137-144:
+ * a frame-sized RGBA8 texture alpha-blended over the tone-mapped image in mrtx_read_rgba8 (exact: 50 % black over 46
+ * reads 23, renderer_video.py:21-25).  NULL removes it. */
+int mrtx_upload_overlay(mrtx_ctx* ctx, const uint8_t* rgba, int32_t h, int32_t w);
+
 /* set_float / set_uint / set_param / set_ambient / add_postproc -- moon_renderer.py:578-600 */
 int mrtx_set_params(mrtx_ctx* ctx, const MrtxParams* p);
 void mrtx_default_params(MrtxParams* p);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mrtx_upload_color": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
     "mrtx_bind_color_device": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
     "mrtx_upload_background": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
+    "mrtx_upload_overlay": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32]),
     "mrtx_set_params": (C.c_int, [_VP, C.POINTER(MrtxParams)]),
     "mrtx_default_params": (None, [C.POINTER(MrtxParams)]),
     "mrtx_set_camera": (C.c_int, [_VP, _D3, _D3, _D3, C.c_double]),

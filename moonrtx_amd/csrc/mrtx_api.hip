@@ -19,7 +19,7 @@
 hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, bool overlay, hipStream_t st);
 hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t npix, uint32_t ns, hipStream_t st);
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
-                                     float invg, hipStream_t st);
+                                     float invg, const uint32_t* overlay, hipStream_t st);
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
                             int tiles_x, int n_tiles, int rank, int world, int slots, hipStream_t st);
 hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
@@ -47,6 +47,7 @@ struct mrtx_ctx {
     float* mip = nullptr; int mip_h = 0, mip_w = 0, mip_shift = 0;   // max-mip of it, cell 2^mip_shift texels (+ one-cell border)
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
+    uint32_t* overlay = nullptr;   // D12: frame-sized RGBA8 blended over the tone-mapped image, or null
     unsigned long long* stats_dev = nullptr;
     FrameCold* cold_dev = nullptr;
     // D11 overlay capsules: host copy in scene coordinates; device copies relative to the Moon centre + tile bins
@@ -410,6 +411,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->mip) (void)hipFree(c->mip);
     if (c->color && c->color_owned) (void)hipFree(c->color);
     if (c->bg) (void)hipFree(c->bg);
+    if (c->overlay) (void)hipFree(c->overlay);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -503,6 +505,21 @@ int mrtx_upload_background(mrtx_ctx* c, const uint8_t* rgba, int32_t h, int32_t 
     HIPCHK(c, hipMemcpy(c->bg, rgba, bytes, hipMemcpyHostToDevice));
     c->bg_h = h; c->bg_w = w;
     c->scene_version++;
+    return MRTX_OK;
+}
+
+int mrtx_upload_overlay(mrtx_ctx* c, const uint8_t* rgba, int32_t h, int32_t w) {
+    if (!c) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (!rgba) {
+        if (c->overlay) { HIPCHK(c, hipFree(c->overlay)); }
+        c->overlay = nullptr;
+        return MRTX_OK;
+    }
+    if (h != c->cfg.height || w != c->cfg.width) return fail(c, MRTX_E_INVALID, "the overlay texture must match the frame (%d x %d)", c->cfg.width, c->cfg.height);
+    const size_t bytes = (size_t)h * w * 4;
+    if (!c->overlay) HIPCHK(c, hipMalloc((void**)&c->overlay, bytes));
+    HIPCHK(c, hipMemcpy(c->overlay, rgba, bytes, hipMemcpyHostToDevice));
     return MRTX_OK;
 }
 
@@ -680,7 +697,7 @@ int mrtx_read_rgba8(mrtx_ctx* c, uint8_t* out) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int64_t npix = (int64_t)c->cfg.width * c->cfg.height;
     HIPCHK(c, mrtx_launch_resolve_rgba8(c->accum, (uint32_t*)c->scratch, npix, c->blocks_done * c->prm.spp_per_launch,
-                                        c->prm.tonemap_exposure, 1.0f / c->prm.tonemap_gamma, c->stream));
+                                        c->prm.tonemap_exposure, 1.0f / c->prm.tonemap_gamma, c->overlay, c->stream));
     HIPCHK(c, hipMemcpyAsync(out, c->scratch, (size_t)npix * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MRTX_OK;

@@ -817,14 +817,24 @@ __device__ __forceinline__ uint32_t tone8(float v, float expo, float invg) {
     t = fminf(t, 1.0f);
     return (uint32_t)floorf(fmaf(t, 255.0f, 0.5f));
 }
+// D12 "Overlay" post-process (renderer_video.py:15-27, :137-144): a frame-sized RGBA8 texture blended over the
+// tone-mapped 8-bit image with exact alpha compositing, out = round((src*(255-a) + ov*a) / 255)
+// -- an opaque black patch gives 0, a 50 % (a = 128) black patch over 46 gives 23.
+__device__ __forceinline__ uint32_t blend8(uint32_t src, uint32_t ov, uint32_t a) {
+    return (src * (255u - a) + ov * a + 127u) / 255u;
+}
 __global__ void resolve_rgba8_kernel(const float4* __restrict__ accum, uint32_t* __restrict__ out, int64_t n,
-                                     uint32_t nsamples, float expo, float invg) {
+                                     uint32_t nsamples, float expo, float invg, const uint32_t* __restrict__ overlay) {
     const float ns = (float)nsamples;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 a = accum[i];
-        uint32_t px = 0xFF000000u;
-        if (nsamples) px |= tone8(a.x / ns, expo, invg) | (tone8(a.y / ns, expo, invg) << 8) | (tone8(a.z / ns, expo, invg) << 16);
-        out[i] = px;
+        uint32_t r = 0, g = 0, b = 0;
+        if (nsamples) { r = tone8(a.x / ns, expo, invg); g = tone8(a.y / ns, expo, invg); b = tone8(a.z / ns, expo, invg); }
+        if (overlay) {
+            const uint32_t o = overlay[i], al = o >> 24;
+            r = blend8(r, o & 255u, al); g = blend8(g, (o >> 8) & 255u, al); b = blend8(b, (o >> 16) & 255u, al);
+        }
+        out[i] = 0xFF000000u | r | (g << 8) | (b << 16);
     }
 }
 
@@ -1099,9 +1109,9 @@ hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t np
     return hipGetLastError();
 }
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
-                                     float invg, hipStream_t st) {
+                                     float invg, const uint32_t* overlay, hipStream_t st) {
     hipLaunchKernelGGL(mrtx::resolve_rgba8_kernel, dim3(grid_for(npix)), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(accum), out, npix, ns, expo, invg);
+                       reinterpret_cast<const float4*>(accum), out, npix, ns, expo, invg, overlay);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,

@@ -130,6 +130,16 @@ class MoonRT:
         self._check(self._lib.mrtx_upload_background(self._ctx, a.ctypes.data, a.shape[0], a.shape[1]),
                     "mrtx_upload_background")
 
+    def upload_overlay(self, rgba):
+        """Frame-sized RGBA8 texture composited over the tone-mapped image (the "Overlay" post-process); None removes it."""
+        if rgba is None:
+            self._check(self._lib.mrtx_upload_overlay(self._ctx, None, 0, 0), "mrtx_upload_overlay")
+            return
+        a = np.ascontiguousarray(rgba, np.uint8)
+        if a.shape != (self.height, self.width, 4):
+            raise ValueError("the overlay must be (height, width, 4) uint8")
+        self._check(self._lib.mrtx_upload_overlay(self._ctx, a.ctypes.data, a.shape[0], a.shape[1]), "mrtx_upload_overlay")
+
     # ---- scene state
     def set_params(self, **kw):
         for k, v in kw.items():

@@ -136,6 +136,9 @@ class TkOptiX:
     def add_postproc(self, stage, refresh=False):
         """add_postproc("Gamma") -- moon_renderer.py:600; "Overlay" -- renderer_video.py:143."""
         self._postproc.append(stage)
+        if stage == "Overlay":
+            with self._padlock:
+                self._bind_overlay()
         if stage not in ("Gamma", "Overlay"):
             self._warn_once("pp" + stage, f"post-processing stage {stage!r} is not implemented")
 
@@ -172,6 +175,7 @@ class TkOptiX:
         with self._padlock:
             self._textures[name] = a
             self._bind_moon_material()
+            self._bind_overlay()
 
     def setup_material(self, name, data):
         """setup_material("flat", {...}) -- moon_renderer.py:647, renderer_labels.py:288."""
@@ -182,6 +186,16 @@ class TkOptiX:
     def update_material(self, name, data, refresh=False):
         """update_material("diffuse", {"ColorTextures": ["moon_color"], ...}) -- moon_renderer.py:617."""
         self.setup_material(name, data)
+
+    OVERLAY_TEXTURE = "frame_overlay"   # renderer_video.py:27
+
+    def _bind_overlay(self):
+        """The "Overlay" stage composites the frame-sized texture named frame_overlay (renderer_video.py:137-144)."""
+        tex = self._textures.get(self.OVERLAY_TEXTURE)
+        if "Overlay" in self._postproc and tex is not None and tex.shape[:2] == (self._height, self._width):
+            self._rt.upload_overlay(tex)
+            if self._frames_done:
+                self._image = self._rt.read_rgba8()
 
     def _bind_moon_material(self):
         moon = self._geoms.get(self._moon_name) if self._moon_name else None

@@ -287,6 +287,30 @@ def test_rgba8_tonemap_within_one_lsb(native_lib, dem_small):
     assert (rgba[..., 3] == 255).all()
 
 
+def test_overlay_postprocess_is_exact_alpha_compositing(native_lib, dem_small):
+    """D12 (renderer_video.py:21-25): an opaque black patch renders 0, a 50 % black patch over 46 renders 23."""
+    from moonrtx_amd.renderer import MoonRT
+    s = named_scene("S2", 64, 48, spp_per_launch=4)
+    rt = MoonRT(s.width, s.height)
+    rt.upload_dem(dem_small); rt.apply_scene(s); rt.render(1)
+    plain = rt.read_rgba8()
+    ov = np.zeros((48, 64, 4), np.uint8)
+    ov[:10, :, 3] = 255                                   # opaque black bar
+    ov[10:20, :, 3] = 128                                 # 50 % black
+    ov[20:30] = (255, 255, 255, 255)                      # opaque white
+    ov[30:40] = (200, 100, 50, 77)
+    rt.upload_overlay(ov)
+    got = rt.read_rgba8()
+    a = ov[..., 3:4].astype(np.uint32)
+    want = (plain[..., :3].astype(np.uint32) * (255 - a) + ov[..., :3].astype(np.uint32) * a + 127) // 255
+    assert np.array_equal(got[..., :3], want.astype(np.uint8)) and (got[..., 3] == 255).all()
+    assert (got[:10, :, :3] == 0).all() and (got[20:30, :, :3] == 255).all() and np.array_equal(got[40:], plain[40:])
+    assert (46 * (255 - 128) + 127) // 255 == 23           # the reference's own check value
+    rt.upload_overlay(None)
+    assert np.array_equal(rt.read_rgba8(), plain)
+    rt.close()
+
+
 def test_device_ldem_pipeline_matches_oracle(native_lib):
     """a1 on the device (data_loader.py:166-247): block mean, scale, +1, /max -- bit exact."""
     from moonrtx_amd.renderer import DeviceBuffer, dem_from_ldem
