@@ -234,6 +234,30 @@ def test_overlay_tubes_match_oracle(native_lib, dem_small):
             rt.close()
 
 
+def test_other_radius_centre_step_and_deep_relief(native_lib, dem_small):
+    """Nothing may be tied to R = 10 at the origin, step 5e-3 or ~1 % relief (skip bounds, mip cell, guards)."""
+    from moonrtx_amd import overlays
+    s = named_scene("S1", 96, 72, spp_per_launch=8)
+    k = 0.37
+    off = np.array([3.0, -2.0, 1.5])
+    s.radius = 10.0 * k
+    s.center = tuple(off)
+    s.eye = tuple(off + k * np.array(s.eye)); s.target = tuple(off)
+    s.light_pos = tuple(off + np.array(s.light_pos)); s.sun_pos = tuple(off + np.array(s.sun_pos))
+    s.marching_step = 2.2e-3; s.marching_step_eps = 1.0e-4; s.scene_epsilon = 4.0e-5
+    check(s, dem_small)
+    pos, edges, r, c = overlays.graticule(radius=10.25 * k, rotation=s.rotation, tube=0.02 * k)
+    caps = overlays.graph_to_capsules(pos + off, edges, r, c)
+    lin_h, hits_h, st_h, _ = render_hip(s, dem_small, capsules=caps, tile=(16, 16))
+    lin_o, hits_o, st_o = render_oracle(s, dem_small, capsules=caps)
+    assert_bit_equal(lin_h, lin_o, "scaled scene with overlay"); assert_bit_equal(hits_h, hits_o, "scaled hits")
+    # 10 % relief, coarse DEM, big steps relative to the texel
+    rng = np.random.default_rng(5)
+    deep = (0.9 + 0.1 * rng.random((40, 80))).astype(np.float32); deep[7, 9] = 1.0
+    s2 = named_scene("S1", 80, 60, spp_per_launch=8); s2.path_seg_min, s2.path_seg_max = 2, 3
+    check(s2, deep)
+
+
 def test_wide_addressing_path_matches(native_lib, dem_small):
     """DEMs above 4 GiB (downscale 1: 17 GB) take 64-bit byte offsets; force that path on a small DEM."""
     from moonrtx_amd import _lib
