@@ -727,30 +727,44 @@ __device__ __forceinline__ float tree_sum(float v) {
 }
 
 // One wave = 64 (pixel, sample) pairs: P = 64/S pixels (PW x PH block) x S samples in adjacent lanes.
-// One 256-thread workgroup = one 16x16-pixel sub-tile of a sharding tile.
+// One workgroup = MRTX_WG_WAVES waves over a (MRTX_WG_TILE x MRTX_WG_TILE)-pixel sub-tile of a sharding
+// tile (never smaller than one wave's pixel block).  Measured at cfg3 (profiles/r01g_wgtile.txt):
+// 4 waves x 16x16 px 21.1 ms, 8x8 18.5, 4x4 17.2, 2x2 15.7; 1 wave x 1 px 15.15 ms.  Per-pixel march cost
+// varies ~20x between disc centre and limb, so the finest grain lets the dispatcher balance the CUs and
+// no wave slot waits on a slower sibling of its workgroup.
+#ifndef MRTX_WG_TILE
+#define MRTX_WG_TILE 1
+#endif
+#ifndef MRTX_WG_WAVES
+#define MRTX_WG_WAVES 1
+#endif
 #ifndef MRTX_MIN_WAVES
 #define MRTX_MIN_WAVES 5   // 94 VGPRs, 5 waves/SIMD, no spill: best of {4,5,6,8} measured (profiles/)
 #endif
 template <int S, bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
-__global__ void __launch_bounds__(256, MRTX_MIN_WAVES) render_kernel(const FrameC f) {
+__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MRTX_MIN_WAVES) render_kernel(const FrameC f) {
     constexpr int P = 64 / S;
     constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;
     constexpr int PH = P / PW;
-    constexpr int JX = 16 / PW, JY = 16 / PH, NJOBS = JX * JY;
+    // workgroup tile edge in pixels: MRTX_WG_TILE, but at least two jobs wide so the 4 waves all have work
+    constexpr int WGMIN = MRTX_WG_WAVES > 2 ? 2 * PW : MRTX_WG_WAVES > 1 ? 2 * PH : PW;
+    constexpr int WGT = (WGMIN > MRTX_WG_TILE) ? WGMIN : MRTX_WG_TILE;
+    constexpr int WGS = WGT == 16 ? 4 : WGT == 8 ? 3 : WGT == 4 ? 2 : WGT == 2 ? 1 : 0;
+    constexpr int JX = WGT / PW, JY = WGT / PH, NJOBS = JX * JY;
     __shared__ unsigned int lds_cnt[ST_N];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD-aware remap: consecutive blockIdx values go to XCDs round-robin, so block b and b+8 share
     // an XCD (and its L2).  Give XCD x the sharding tiles x, x+8, x+16, ... and let it walk the
     // sub-tiles of one tile back to back.
-    const int subs_x = f.tile_w >> 4, subs = subs_x * (f.tile_h >> 4);
+    const int subs_x = f.tile_w >> WGS, subs = subs_x * (f.tile_h >> WGS);
     const int b = blockIdx.x, xcd = b & 7, g = b >> 3;
     const int li = (g / subs) * 8 + xcd, sub = g % subs;
     if (li >= f.n_active) return;
     const int lt = f.tile_list ? f.tile_list[li] : li;
     const int t = lt * f.world + f.rank;
     const int tx = t % f.tiles_x, ty = t / f.tiles_x;
-    const int px0 = tx * f.tile_w + (sub % subs_x) * 16, py0 = ty * f.tile_h + (sub / subs_x) * 16;
+    const int px0 = tx * f.tile_w + (sub % subs_x) * WGT, py0 = ty * f.tile_h + (sub / subs_x) * WGT;
     if (px0 >= f.W || py0 >= f.H) return;
 
     uint32_t cnt[ST_N];
@@ -762,7 +776,7 @@ __global__ void __launch_bounds__(256, MRTX_MIN_WAVES) render_kernel(const Frame
     }
 
     const int p = lane / S, s = lane % S;
-    for (int job = wv; job < NJOBS; job += 4) {
+    for (int job = wv; job < NJOBS; job += MRTX_WG_WAVES) {
         const int jx = job % JX, jy = job / JX;
         const int x = px0 + jx * PW + (p % PW), y = py0 + jy * PH + (p / PW);
         if (px0 + jx * PW >= f.W || py0 + jy * PH >= f.H) continue;  // wave-uniform
@@ -1074,9 +1088,14 @@ __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, in
 // launch wrappers (called from mrtx_api.hip)
 extern "C++" {
 hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, bool overlay, hipStream_t st) {
-    const int subs = (f.tile_w >> 4) * (f.tile_h >> 4);
+    const int P = 64 / S;
+    const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1;
+    const int PH = P / PW;
+    const int wgmin = MRTX_WG_WAVES > 2 ? 2 * PW : MRTX_WG_WAVES > 1 ? 2 * PH : PW;
+    const int wgt = (wgmin > MRTX_WG_TILE) ? wgmin : MRTX_WG_TILE;
+    const int subs = (f.tile_w / wgt) * (f.tile_h / wgt);
     const int groups = (f.n_active + 7) / 8;
-    const dim3 grid((unsigned)(groups * subs * 8)), block(256);
+    const dim3 grid((unsigned)(groups * subs * 8)), block(64 * MRTX_WG_WAVES);
     if (grid.x == 0) return hipSuccess;
     const bool wide = f.dem_wide != 0;
 #define MRTX_LAUNCH(SV, ST, WD, BN, OV) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, BN, OV>), grid, block, 0, st, f)
