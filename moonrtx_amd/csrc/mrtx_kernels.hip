@@ -34,6 +34,17 @@ __device__ constexpr float kPi = 3.14159274101257324f;
 __device__ constexpr float kHalfPi = 1.57079637050628662f;
 __device__ constexpr float kInv255 = 0.003921568859368563f;
 
+// -DMRTX_PROF (tools/build_variant.sh prof -DMRTX_PROF): s_memtime section timers, summed per wave into g_prof.
+// A measurement build only; the shipped library never defines it.
+#ifdef MRTX_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_BEGIN(i) const unsigned long long _pt##i = __builtin_readcyclecounter()
+#define PROF_END(i) cnt[i] += (uint32_t)(__builtin_readcyclecounter() - _pt##i)
+#else
+#define PROF_BEGIN(i)
+#define PROF_END(i)
+#endif
+
 enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_FETCH, ST_MIP, ST_BOUNCE, ST_N };
 
 // atan(q) ~= q * P(q^2) on [0,1], |err| <= 1.3e-7
@@ -293,6 +304,10 @@ __device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, f
         const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
         const bool bel = below_seg<WIDE, EXACTABLE>(f, sg, sk, pa, pb, pc, r2);
         if (STATS) { cnt[ST_HEIGHT] += in ? 1u : 0u; cnt[ST_FETCH]++; }
+#ifdef MRTX_PROF
+        cnt[11] += 1;                                    // wave-level step iterations
+        cnt[12] += (uint32_t)__popcll(__ballot(true));   // lanes evaluating in them
+#endif
         hit = in & bel;
         go = in & !bel;
         sk_out = sk;
@@ -335,12 +350,20 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
     int ka = 0;
     while (go) {
         float rowB, colB, q2B;
+        PROF_BEGIN(6);
         seg_setup<STATS>(f, oa, ob, oc, da, db, dc, rq, ka, rowA, colA, q2A, sg, rowB, colB, q2B, cnt);
+        PROF_END(6);
+        PROF_BEGIN(7);
         if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, 1, sg.jlo - 1);
         if (__ballot(sg.exact) != 0ull)
             step_loop<WIDE, PRIMARY, STATS, true>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
         else
             step_loop<WIDE, PRIMARY, STATS, false>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+        PROF_END(7);
+#ifdef MRTX_PROF
+        cnt[8] += 1;                                     // wave-level segments
+        cnt[9] += (uint32_t)__popcll(__ballot(true));    // lanes alive in them
+#endif
         if (go) {
             // still marching after the last evaluated step: did the ray end inside the skipped tail?
             if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, max(sg.jhi + 1, 1), SEG_N);
@@ -546,6 +569,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     o.c0 = o.c1 = o.c2 = 0.0f; o.hitflag = 0.0f;
     o.h0 = o.h1 = o.h2 = o.h3 = 0.0f;
     if (STATS) cnt[ST_PRIMARY]++;
+    PROF_BEGIN(1);
 
     // D1: jittered pinhole ray
     const float fx = (float)x + u0, fy = (float)y + u1;
@@ -588,6 +612,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     }
     bool hit = false;
     float pa = 0.f, pb = 0.f, pc = 0.f, da = 0.f, db = 0.f, dc = 0.f, lo = 0.0f;
+    PROF_END(1);
     if (on_sphere && !cap_front) {
         const double pe0 = CF(f)->oc[0] + t0 * Dx, pe1 = CF(f)->oc[1] + t0 * Dy, pe2 = CF(f)->oc[2] + t0 * Dz;
         pa = (float)((CF(f)->M[0][0] * pe0 + CF(f)->M[0][1] * pe1) + CF(f)->M[0][2] * pe2);
@@ -599,7 +624,10 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         const float smax = (float)(t1 - t0);
         Seg sg;
         float hi = 0.0f;
+        PROF_BEGIN(2);
         hit = march<WIDE, true, STATS>(f, pa, pb, pc, da, db, dc, smax, sg, hi, cnt);
+        PROF_END(2);
+        PROF_BEGIN(3);
         if (hit) {
             // hi = (float)k * step of the first sample below; k recovered exactly (|k*step/step - k| << 0.5)
             const int k = (int)rintf(hi * f.inv_step);
@@ -613,6 +641,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
             }
             if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
         }
+        PROF_END(3);
     }
 
     if (OVERLAY && !hit && cap >= 0) {
@@ -648,7 +677,9 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     // ---- the path: vertex 1 is the primary hit; BOUNCE continues it (D6, set_uint("path_seg_range", min, max))
     if (STATS) cnt[ST_HITS]++;
     Vertex v;
+    PROF_BEGIN(4);
     hit_vertex<STATS, WIDE>(f, fmaf(lo, da, pa), fmaf(lo, db, pb), fmaf(lo, dc, pc), v, cnt);
+    PROF_END(4);
     o.hitflag = 1.0f;
     o.h0 = CF(f)->centerf[0] + fmaf(v.pc, CF(f)->Mf[2][0], fmaf(v.pb, CF(f)->Mf[1][0], v.pa * CF(f)->Mf[0][0]));
     o.h1 = CF(f)->centerf[1] + fmaf(v.pc, CF(f)->Mf[2][1], fmaf(v.pb, CF(f)->Mf[1][1], v.pa * CF(f)->Mf[0][1]));
@@ -659,7 +690,9 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     uint32_t seg = 1;
     float ul1 = u2, ul2 = u3;
     for (;;) {
+        PROF_BEGIN(5);
         const float wgt = direct_light<STATS, WIDE>(f, v, ul1, ul2, cnt);
+        PROF_END(5);
         o.c0 = fmaf(t0r * v.al0, wgt, o.c0);
         o.c1 = fmaf(t1r * v.al1, wgt, o.c1);
         o.c2 = fmaf(t2r * v.al2, wgt, o.c2);
@@ -767,7 +800,15 @@ __global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MRTX_MIN_WAVES) render_ker
     const int px0 = tx * f.tile_w + (sub % subs_x) * WGT, py0 = ty * f.tile_h + (sub / subs_x) * WGT;
     if (px0 >= f.W || py0 >= f.H) return;
 
+#ifdef MRTX_PROF
+    uint32_t cnt[16];
+    if (!STATS) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) cnt[i] = 0;
+    }
+#else
     uint32_t cnt[ST_N];
+#endif
     if (STATS) {
 #pragma unroll
         for (int i = 0; i < ST_N; i++) cnt[i] = 0;
@@ -791,7 +832,9 @@ __global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MRTX_MIN_WAVES) render_ker
         o.h0 = o.h1 = o.h2 = o.h3 = 0.f;
         for (uint32_t blk = 0; blk < f.n_blocks; blk++) {
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
+            PROF_BEGIN(0);
             if (inb) trace_sample<STATS, WIDE, BOUNCE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            PROF_END(0);
             s0 += tree_sum<S>(o.c0);
             s1 += tree_sum<S>(o.c1);
             s2 += tree_sum<S>(o.c2);
@@ -803,6 +846,13 @@ __global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MRTX_MIN_WAVES) render_ker
         }
     }
 
+#ifdef MRTX_PROF
+    if (!STATS && lane == 0 && (((uint32_t)(blockIdx.x >> 3) * 2654435761u) >> 26) == 0u) {   // 1/64 of the waves
+        cnt[10] = 1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) atomicAdd(&g_prof[i], (unsigned long long)cnt[i]);
+    }
+#endif
     if (STATS) {
 #pragma unroll
         for (int i = 0; i < ST_N; i++) {
@@ -1117,6 +1167,17 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, b
 #undef MRTX_LAUNCH
     return hipGetLastError();
 }
+
+#ifdef MRTX_PROF
+extern "C" __attribute__((visibility("default"))) int mrtx_prof_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mrtx::g_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mrtx::g_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 static inline unsigned grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Section timers of render_kernel (a -DMRTX_PROF build): MOONRT_LIB=ab/libmoonrt_prof.so python tools/prof_sections.py
+
+s_memtime deltas summed over all waves of one cfg3 launch; shares are of the summed per-wave trace time."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import WORKLOADS
+from moonrtx_amd import _lib
+from moonrtx_amd.renderer import MoonRT, synth_ldem, synth_color, dem_from_ldem
+from moonrtx_amd.scene import named_scene
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+sc = sys.argv[2] if len(sys.argv) > 2 else "S1"
+W, H, spp, dem_h, dem_w, col_shape = WORKLOADS[wl]
+src = synth_ldem(dem_h, dem_w, device=0)
+dem_buf, _ = dem_from_ldem(src, dem_h, dem_w, 1, device=0)
+src.free()
+col = synth_color(col_shape[0], col_shape[1], device=0)
+scene = named_scene(sc, W, H, spp_per_launch=64)
+rt = MoonRT(W, H, device=0)
+rt.bind_dem(dem_buf, dem_h, dem_w)
+rt.bind_color(col, col_shape[0], col_shape[1])
+rt.apply_scene(scene)
+rt.set_params(flags=0)
+lib = _lib.load()
+fn = lib.mrtx_prof_read
+fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+out = (C.c_ulonglong * 16)()
+rt.reset(); rt.render(1)
+fn(out, 1)
+rt.reset(); st = rt.render(1)
+fn(out, 1)
+v = list(out)
+names = ["trace total", "primary setup", "primary march", "bisect", "hit_vertex", "direct_light (incl. shadow march)",
+         "seg_setup (all marches)", "step loops (all marches)"]
+print(f"{wl} {sc}: kernel {st['kernel_ms']:.3f} ms, waves {v[10]}")
+for i, n in enumerate(names):
+    print(f"  {n:36s} {v[i]:16d} ticks  {v[i] / v[0]:.3f}")
+print(f"  wave-level step iterations {v[11]} ({v[11] / max(1, v[10]):.1f} per wave), mean lanes evaluating {v[12] / max(1, v[11]):.1f}")
+print(f"  wave-level segments {v[8]}, mean lanes alive in a segment {v[9] / max(1, v[8]):.1f}")
