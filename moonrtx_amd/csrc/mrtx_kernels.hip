@@ -288,31 +288,77 @@ __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float 
 }
 
 // The steps jlo..jhi of one segment, per lane.  Branch-free body: the DEM is sampled even on the step that
-// turns out to lie outside (its result is discarded; at most one wasted sample per ray), so the only control
-// flow is the loop-back on the ballot of lanes still stepping.
-template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE>
+// turns out to lie outside (its result is discarded), so the only control flow is the loop-back on the
+// ballot of lanes still stepping.
+//
+// The kernel is bound by DEPENDENT-LOAD LATENCY (each round trip ~1-2 k cycles under load, five waves per SIMD
+// to hide it), so the plain-quadratic variant evaluates MRTX_STEP_BATCH consecutive steps per iteration: all
+// their DEM loads are issued back to back, then the steps are tested in march order and everything after the
+// first terminating one is discarded.  Same evaluations, same order, same result; a few wasted fetches.
+// Measured at cfg3: batch 1 15.19 ms, 2 14.83, 4 16.57 (+11 % fetches), 8 18.55.
+#ifndef MRTX_STEP_BATCH
+#define MRTX_STEP_BATCH 2
+#endif
+template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE, int BATCH>
 __device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                           float smax, const Seg& sg, int ka, bool& go, bool& hit, float& sk_out,
                                           uint32_t* cnt) {
     int j = sg.jlo;
     bool more = j <= sg.jhi;
-    while (more) {
-        const int k = ka + j;
-        const float sk = (float)k * f.step;
-        const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
-        const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
-        const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
-        const bool bel = below_seg<WIDE, EXACTABLE>(f, sg, sk, pa, pb, pc, r2);
-        if (STATS) { cnt[ST_HEIGHT] += in ? 1u : 0u; cnt[ST_FETCH]++; }
+    if (EXACTABLE || BATCH == 1) {
+        while (more) {
+            const int k = ka + j;
+            const float sk = (float)k * f.step;
+            const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
+            const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+            const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
+            const bool bel = below_seg<WIDE, EXACTABLE>(f, sg, sk, pa, pb, pc, r2);
+            if (STATS) { cnt[ST_HEIGHT] += in ? 1u : 0u; cnt[ST_FETCH]++; }
 #ifdef MRTX_PROF
-        cnt[11] += 1;                                    // wave-level step iterations
-        cnt[12] += (uint32_t)__popcll(__ballot(true));   // lanes evaluating in them
+            cnt[11] += 1;                                    // wave-level step iterations
+            cnt[12] += (uint32_t)__popcll(__ballot(true));   // lanes evaluating in them
 #endif
-        hit = in & bel;
-        go = in & !bel;
-        sk_out = sk;
-        j++;
-        more = go & (j <= sg.jhi);
+            hit = in & bel;
+            go = in & !bel;
+            sk_out = sk;
+            j++;
+            more = go & (j <= sg.jhi);
+        }
+    } else {
+        constexpr int B = BATCH;
+        while (more) {
+            float surf[B];
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                // steps past jhi are evaluated at the segment's last step instead (inside the quadratic's range)
+                const float u = ((float)(ka + min(j + i, SEG_N)) * f.step - sg.sa) * f.inv_step;   // as below_seg()
+                const float rowf = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra);
+                const float colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
+                surf[i] = f.Rf * dem_march<WIDE>(f, rowf, colf);
+            }
+            if (STATS) cnt[ST_FETCH] += B;
+#ifdef MRTX_PROF
+            cnt[11] += 1;
+            cnt[12] += (uint32_t)__popcll(__ballot(true));
+#endif
+            bool act = true;
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const int k = ka + j + i;
+                const float sk = (float)k * f.step;
+                const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
+                const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+                const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
+                const bool bel = r2 <= surf[i] * surf[i];
+                if (STATS) cnt[ST_HEIGHT] += (act & in) ? 1u : 0u;
+                hit = act ? (in & bel) : hit;
+                go = act ? (in & !bel) : go;
+                sk_out = act ? sk : sk_out;
+                act = act & go & (j + i + 1 <= sg.jhi);
+            }
+            j += B;
+            more = act;
+        }
     }
 }
 
@@ -337,7 +383,7 @@ __device__ __forceinline__ uint32_t count_in_steps(const FrameC& f, float oa, fl
 // PRIMARY: stop when s_k > smax (left the bounding sphere); shadow rays: stop when r^2 > R^2.
 // A lane drops out of the exec mask when it hits or leaves, and the wave leaves the loop when no lane is still
 // marching.  f.kmax is a multiple of SEG_N.
-template <bool WIDE, bool PRIMARY, bool STATS>
+template <bool WIDE, bool PRIMARY, bool STATS, int BATCH>
 __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                       float smax, Seg& sg, float& sk_hit, uint32_t* cnt) {
     float rowA, colA, q2A;
@@ -356,13 +402,15 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
         PROF_BEGIN(7);
         if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, 1, sg.jlo - 1);
         if (__ballot(sg.exact) != 0ull)
-            step_loop<WIDE, PRIMARY, STATS, true>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+            step_loop<WIDE, PRIMARY, STATS, true, 1>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
         else
-            step_loop<WIDE, PRIMARY, STATS, false>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+            step_loop<WIDE, PRIMARY, STATS, false, BATCH>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
         PROF_END(7);
 #ifdef MRTX_PROF
         cnt[8] += 1;                                     // wave-level segments
         cnt[9] += (uint32_t)__popcll(__ballot(true));    // lanes alive in them
+        cnt[PRIMARY ? 13 : 14] += (__ballot(sg.jlo <= sg.jhi) == 0ull) ? 1u : 0u;   // wave-level segments nobody steps in
+        cnt[15] += PRIMARY ? 1u : 0u;
 #endif
         if (go) {
             // still marching after the last evaluated step: did the ray end inside the skipped tail?
@@ -466,7 +514,7 @@ __device__ __forceinline__ void hit_vertex(const FrameC& f, float ha, float hb, 
 
 // D5: one sample of the spherical light from a vertex, shadow ray marched through the same height field;
 // returns radiance * solid angle / pi * cos(theta_i) * visibility
-template <bool STATS, bool WIDE>
+template <bool STATS, bool WIDE, int BATCH>
 __device__ __forceinline__ float direct_light(const FrameC& f, const Vertex& v, float u2, float u3, uint32_t* cnt) {
     const float eps = CF(f)->scene_eps;
     const float oa = fmaf(eps, v.na, v.pa), ob = fmaf(eps, v.nb, v.pb), oc = fmaf(eps, v.nc, v.pc);
@@ -494,7 +542,7 @@ __device__ __forceinline__ float direct_light(const FrameC& f, const Vertex& v, 
     if (STATS) cnt[ST_SHADOW]++;
     Seg ssg;
     float sk_occ;
-    if (march<WIDE, false, STATS>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return 0.0f;
+    if (march<WIDE, false, STATS, BATCH>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return 0.0f;
     return (CF(f)->rad2 * omc) * cosi;
 }
 
@@ -562,6 +610,7 @@ struct SampleOut {
 template <bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
+    constexpr int BATCH = BOUNCE ? 1 : MRTX_STEP_BATCH;   // incoherent bounce rays waste the speculative fetches
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
     const uint32_t kp = mix32(pix + CF(f)->key0);
     const uint32_t ks = mix32(kp ^ (gs * 0x85EBCA6Bu + 1u));
@@ -625,7 +674,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         Seg sg;
         float hi = 0.0f;
         PROF_BEGIN(2);
-        hit = march<WIDE, true, STATS>(f, pa, pb, pc, da, db, dc, smax, sg, hi, cnt);
+        hit = march<WIDE, true, STATS, BATCH>(f, pa, pb, pc, da, db, dc, smax, sg, hi, cnt);
         PROF_END(2);
         PROF_BEGIN(3);
         if (hit) {
@@ -691,7 +740,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     float ul1 = u2, ul2 = u3;
     for (;;) {
         PROF_BEGIN(5);
-        const float wgt = direct_light<STATS, WIDE>(f, v, ul1, ul2, cnt);
+        const float wgt = direct_light<STATS, WIDE, BATCH>(f, v, ul1, ul2, cnt);
         PROF_END(5);
         o.c0 = fmaf(t0r * v.al0, wgt, o.c0);
         o.c1 = fmaf(t1r * v.al1, wgt, o.c1);
@@ -724,7 +773,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         if (STATS) cnt[ST_BOUNCE]++;
         Seg bsg;
         float bhi = 0.0f;
-        if (!march<WIDE, false, STATS>(f, boa, bob, boc, bda, bdb, bdc, 0.0f, bsg, bhi, cnt)) {
+        if (!march<WIDE, false, STATS, BATCH>(f, boa, bob, boc, bda, bdb, bdc, 0.0f, bsg, bhi, cnt)) {
             if (CF(f)->bg) {   // the path leaves the Moon: environment radiance along its direction (scene frame)
                 const float ex = fmaf(bdc, CF(f)->Mf[2][0], fmaf(bdb, CF(f)->Mf[1][0], bda * CF(f)->Mf[0][0]));
                 const float ey = fmaf(bdc, CF(f)->Mf[2][1], fmaf(bdb, CF(f)->Mf[1][1], bda * CF(f)->Mf[0][1]));
@@ -772,10 +821,14 @@ __device__ __forceinline__ float tree_sum(float v) {
 #define MRTX_WG_WAVES 1
 #endif
 #ifndef MRTX_MIN_WAVES
-#define MRTX_MIN_WAVES 5   // 94 VGPRs, 5 waves/SIMD, no spill: best of {4,5,6,8} measured (profiles/)
+#define MRTX_MIN_WAVES 5   // 93 VGPRs, 5 waves/SIMD, no spill: 4 measures the same, 6 and 8 slower (spills)
+#endif
+#ifndef MRTX_MIN_WAVES_BOUNCE
+#define MRTX_MIN_WAVES_BOUNCE 5   // 8 spilled VGPRs at 5 waves/SIMD still beat 4 waves without spills (36.1 vs 39.8 ms)
 #endif
 template <int S, bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
-__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MRTX_MIN_WAVES) render_kernel(const FrameC f) {
+__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, BOUNCE ? MRTX_MIN_WAVES_BOUNCE : MRTX_MIN_WAVES)
+render_kernel(const FrameC f) {
     constexpr int P = 64 / S;
     constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;
     constexpr int PH = P / PW;
