@@ -336,7 +336,6 @@ __device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, f
                 const float colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
                 surf[i] = f.Rf * dem_march<WIDE>(f, rowf, colf);
             }
-            if (STATS) cnt[ST_FETCH] += B;
 #ifdef MRTX_PROF
             cnt[11] += 1;
             cnt[12] += (uint32_t)__popcll(__ballot(true));
@@ -350,7 +349,7 @@ __device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, f
                 const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
                 const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
                 const bool bel = r2 <= surf[i] * surf[i];
-                if (STATS) cnt[ST_HEIGHT] += (act & in) ? 1u : 0u;
+                if (STATS) { cnt[ST_HEIGHT] += (act & in) ? 1u : 0u; cnt[ST_FETCH] += act ? 1u : 0u; }   // speculative fetches are not credited
                 hit = act ? (in & bel) : hit;
                 go = act ? (in & !bel) : go;
                 sk_out = act ? sk : sk_out;
