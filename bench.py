@@ -206,7 +206,7 @@ def main():
             "config": {"workload": f"{args.workload}: {W}x{H}, {spp} spp, DEM {dem_h}x{dem_w} f32"
                                    + (f", colour {col_shape[0]}x{col_shape[1]} RGBA8" if col_shape else ", grey albedo")
                                    + f", scene {args.scene}",
-                       "parallelism": f"image tiles 32x32 round-robin over {world} GPU(s)"
+                       "parallelism": f"image tiles 32x32 dealt round-robin (2-D lattice) over {world} GPU(s), active tiles gathered to rank 0"
                                       + (", RCCL gather of float4 radiance+hits to rank 0" if world > 1 else ""),
                        "march": "step 5e-3, eps 3e-4, scene_epsilon 1e-4, 1 light sample + shadow ray per path vertex, "
                                 f"path_seg_range {tuple(args.path_seg)}" + (" (direct light only)" if args.path_seg[1] <= 1 else "")},

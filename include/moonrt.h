@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRTX_ABI_VERSION 3
+#define MRTX_ABI_VERSION 4
 
 enum {
     MRTX_OK = 0,
@@ -37,7 +37,9 @@ enum {
 typedef struct mrtx_ctx mrtx_ctx;
 
 /* Frame + sharding description.  rank/world shard the image in tiles of tile_w x tile_h
- * pixels: tile t (raster order) belongs to rank (t % world).  world == 1 renders everything. */
+ * pixels: tile t belongs to rank (t % world), where t numbers the tiles in raster order with a cyclic shift of s
+ * columns per tile row -- t = ty * tiles_x + (tx + s * ty) % tiles_x, s = the smallest odd number >= 3 coprime to
+ * world -- so that a rank's tiles form a 2-D lattice, not whole columns.  world == 1 renders everything. */
 typedef struct MrtxConfig {
     int32_t device;          /* HIP device ordinal                                             */
     int32_t width, height;   /* TkOptiX(width=, height=)            moon_renderer.py:571-573   */
@@ -169,10 +171,17 @@ int mrtx_samples_done(mrtx_ctx* ctx, uint32_t* out);
  * A rank packs the tiles it owns (linear float4 radiance followed by float4 hits) into a compact
  * device buffer the caller provides (e.g. a torch tensor handed to an RCCL gather), and rank 0
  * scatters the gathered buffers back into frame order. */
-int mrtx_shard_bytes(mrtx_ctx* ctx, int32_t rank, uint64_t* out);   /* size of rank's packed buffer */
+int mrtx_shard_bytes(mrtx_ctx* ctx, int32_t rank, uint64_t* out);   /* upper bound of a packed buffer (all tiles) */
+/* Bytes the exchange moves per rank for the scene as it stands.  While the host-side sky cull is in force (no
+ * environment map, no overlay geometry, MRTX_F_NO_CULL clear) only the tiles the cull keeps travel: every rank
+ * derives every rank's tile list from its own copy of the scene -- identical on all ranks by contract -- so the
+ * layout is never negotiated.  Equal on every rank (padded to the longest list), <= mrtx_shard_bytes().
+ * pack/unpack below use this layout; a buffer of mrtx_shard_bytes() is always large enough. */
+int mrtx_shard_bytes_active(mrtx_ctx* ctx, uint64_t* out);
 int mrtx_pack_shard(mrtx_ctx* ctx, void* dev_dst, void* hip_stream);
 int mrtx_unpack_shard(mrtx_ctx* ctx, int32_t src_rank, const void* dev_src, void* hip_stream);
-/* Same for every peer at once: dev_srcs[r] is rank r's packed buffer (entry 0 is ignored); one synchronisation. */
+/* Same for every peer at once: dev_srcs[r] is rank r's packed buffer (the own rank's entry is ignored); one
+ * synchronisation.  Tiles of peers that held an earlier view's data and are sky in this one are zeroed. */
 int mrtx_unpack_all(mrtx_ctx* ctx, const void* const* dev_srcs, int32_t n);
 
 /* Raw device pointers of the context's buffers (for zero-copy wrapping by the host side). */

@@ -21,9 +21,12 @@ hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t np
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
                                      float invg, const uint32_t* overlay, hipStream_t st);
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
-                            int tiles_x, int n_tiles, int rank, int world, int slots, hipStream_t st);
+                            int tiles_x, int n_tiles, int rank, int world, int slots, const int32_t* list, int shift, hipStream_t st);
 hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
-                              int tiles_x, int n_tiles, int src_rank, int world, int slots, hipStream_t st);
+                              int tiles_x, int n_tiles, int src_rank, int world, int slots, const int32_t* list, int shift,
+                              hipStream_t st);
+hipError_t mrtx_launch_zero_tiles(float* accum, float* hits, const int32_t* tiles, int n, int W, int H, int tw, int th,
+                                  int tiles_x, int shift, hipStream_t st);
 hipError_t mrtx_launch_ldem(const int16_t* src, float* dst, int h, int w, int d, unsigned int* max_bits,
                             hipStream_t st);
 hipError_t mrtx_launch_synth_ldem(int16_t* dst, int h, int w, uint32_t seed, hipStream_t st);
@@ -37,7 +40,7 @@ hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out
 struct mrtx_ctx {
     MrtxConfig cfg{};
     MrtxParams prm{};
-    int tiles_x = 0, tiles_y = 0, n_tiles = 0, n_local = 0, slots = 0;
+    int tiles_x = 0, tiles_y = 0, n_tiles = 0, n_local = 0, slots = 0, tile_shift = 3;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float* accum = nullptr;
@@ -62,6 +65,18 @@ struct mrtx_ctx {
     uint64_t culled_px_cached = 0;
     uint64_t scene_version = 1, cull_version = 0;   // bumped by every setter that can change the cull
     std::vector<uint8_t> tile_dirty;     // local tiles written since the buffers were last zeroed
+    // gather layout: with the sky cull in force only ACTIVE tiles travel (every rank derives every rank's list from the
+    // scene, which is identical on all ranks by contract); act_slots = the longest list, shorter ones are padded with -1
+    std::vector<std::vector<int32_t>> act_lists;
+    uint64_t act_version = 0;
+    bool act_on = false;
+    int act_slots = 0;
+    int32_t* act_dev = nullptr;          // world x act_slots, uploaded for act_uploaded_version
+    size_t act_dev_cap = 0;
+    uint64_t act_uploaded_version = 0;
+    std::vector<uint8_t> peer_written;   // root: global tiles of other ranks that hold unpacked data
+    int32_t* stale_dev = nullptr;
+    size_t stale_cap = 0;
     uint32_t blocks_done = 0;
     double eye[3] = {0, -300, 0}, target[3] = {0, 0, 0}, up[3] = {0, 0, 1}, vfov = 4.2421875;
     double center[3] = {0, 0, 0}, radius = 10.0, u[3] = {0, 0, 1}, v[3] = {0, -1, 0};
@@ -194,7 +209,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     f.dem_maxidx = (uint32_t)((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 4) + (uint64_t)(c->dem_w + 2));
     f.dem_wide = ((uint64_t)(c->dem_h + 4) * (uint64_t)(c->dem_w + 4) * 4ull > 0xFFFFFFFFull) ? 1 : 0;
     f.tile_w = c->cfg.tile_w; f.tile_h = c->cfg.tile_h;
-    f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y;
+    f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.tile_shift = c->tile_shift;
     f.rank = c->cfg.rank; f.world = c->cfg.world; f.n_local_tiles = c->n_local;
     f.accum = c->accum; f.hits = c->hits; f.stats = c->stats_dev;
     f.tile_list = nullptr; f.n_active = c->n_local;
@@ -243,7 +258,7 @@ int build_capsule_bins(mrtx_ctx* c) {
         }
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
-                const int t = ty * c->tiles_x + tx;
+                const int t = mrtx_tile_id(tx, ty, c->tiles_x, c->tile_shift);
                 if (t % c->cfg.world == c->cfg.rank) bins[(size_t)(t / c->cfg.world)].push_back((int32_t)k);
             }
     }
@@ -275,8 +290,10 @@ int build_capsule_bins(mrtx_ctx* c) {
 // cone of its view directions (tile-centre direction, half-angle = largest corner angle + 5 % + 1e-4 rad, pixel
 // extents included so every jittered sample is inside) is disjoint from both objects' cones as seen from the eye.
 // Returns the local tile indices to render and the number of pixels culled.
-void cull_tiles(const mrtx_ctx* c, std::vector<int32_t>& keep, uint64_t& culled_px) {
+void cull_tiles(const mrtx_ctx* c, int rank, std::vector<int32_t>& keep, uint64_t& culled_px) {
     keep.clear(); culled_px = 0;
+    const int n_local = (c->n_tiles - rank + c->cfg.world - 1) / c->cfg.world;
+    const bool own = rank == c->cfg.rank;   // overlay bins exist for the own tiles only (gather_layout() switches off with overlays)
     const int W = c->cfg.width, H = c->cfg.height;
     double wv[3], uv[3], vv[3];
     for (int i = 0; i < 3; i++) wv[i] = c->target[i] - c->eye[i];
@@ -309,9 +326,11 @@ void cull_tiles(const mrtx_ctx* c, std::vector<int32_t>& keep, uint64_t& culled_
         dp = dp > 1.0 ? 1.0 : (dp < -1.0 ? -1.0 : dp);
         return std::acos(dp);
     };
-    for (int lt = 0; lt < c->n_local; lt++) {
-        const int t = lt * c->cfg.world + c->cfg.rank;
-        const int x0 = (t % c->tiles_x) * c->cfg.tile_w, y0 = (t / c->tiles_x) * c->cfg.tile_h;
+    for (int lt = 0; lt < n_local; lt++) {
+        const int t = lt * c->cfg.world + rank;
+        int ttx, tty;
+        mrtx_tile_xy(t, c->tiles_x, c->tile_shift, ttx, tty);
+        const int x0 = ttx * c->cfg.tile_w, y0 = tty * c->cfg.tile_h;
         const int x1 = x0 + c->cfg.tile_w < W ? x0 + c->cfg.tile_w : W, y1 = y0 + c->cfg.tile_h < H ? y0 + c->cfg.tile_h : H;
         bool need = everything;
         if (!need) {
@@ -324,7 +343,7 @@ void cull_tiles(const mrtx_ctx* c, std::vector<int32_t>& keep, uint64_t& culled_
             for (int k = 0; k < 2; k++)
                 if (cones[k].on && ang(d0, cones[k].ax) <= cones[k].half + gamma) need = true;
         }
-        if (!need && !c->caps_off_host.empty() && c->caps_off_host[(size_t)lt + 1] > c->caps_off_host[(size_t)lt]) need = true;   // overlay tubes here
+        if (!need && own && !c->caps_off_host.empty() && c->caps_off_host[(size_t)lt + 1] > c->caps_off_host[(size_t)lt]) need = true;   // overlay tubes here
         if (need) keep.push_back(lt);
         else culled_px += (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
     }
@@ -373,6 +392,7 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
     c->tiles_x = (cfg->width + c->cfg.tile_w - 1) / c->cfg.tile_w;
     c->tiles_y = (cfg->height + c->cfg.tile_h - 1) / c->cfg.tile_h;
     c->n_tiles = c->tiles_x * c->tiles_y;
+    c->tile_shift = mrtx_tile_shift(cfg->world);
     c->slots = (c->n_tiles + cfg->world - 1) / cfg->world;
     c->n_local = (c->n_tiles - cfg->rank + cfg->world - 1) / cfg->world;
     *out = c;  // from here on the caller can read mrtx_last_error and must destroy
@@ -407,6 +427,8 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->caps_off_dev) (void)hipFree(c->caps_off_dev);
     if (c->caps_idx_dev) (void)hipFree(c->caps_idx_dev);
     if (c->tile_list_dev) (void)hipFree(c->tile_list_dev);
+    if (c->act_dev) (void)hipFree(c->act_dev);
+    if (c->stale_dev) (void)hipFree(c->stale_dev);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
     if (c->color && c->color_owned) (void)hipFree(c->color);
@@ -532,6 +554,7 @@ int mrtx_set_params(mrtx_ctx* c, const MrtxParams* p) {
     if (!(p->tonemap_gamma > 0.0f)) return fail(c, MRTX_E_INVALID, "tonemap_gamma must be > 0");
     if (S != c->prm.spp_per_launch && c->blocks_done != 0)
         return fail(c, MRTX_E_STATE, "spp_per_launch cannot change inside an accumulation cycle; reset first");
+    if (p->flags != c->prm.flags) c->scene_version++;   // MRTX_F_NO_CULL changes the cull and the gather layout
     c->prm = *p;
     return MRTX_OK;
 }
@@ -620,7 +643,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     bool culling = false;
     if (!(c->prm.flags & MRTX_F_NO_CULL)) {
         if (c->cull_version != c->scene_version) {
-            cull_tiles(c, c->keep_cached, c->culled_px_cached);
+            cull_tiles(c, c->cfg.rank, c->keep_cached, c->culled_px_cached);
             c->cull_version = c->scene_version;
         }
         culled_px = c->culled_px_cached;
@@ -711,26 +734,112 @@ int mrtx_read_hits(mrtx_ctx* c, float* out) {
     return MRTX_OK;
 }
 
+// The layout both ends of the gather use for the scene as it stands: active tiles only while the sky cull is in force
+// (no environment map, no overlay geometry, culling not disabled), the full layout otherwise.  Every rank derives
+// every rank's list from its own copy of the scene -- identical on all ranks by contract -- so nothing is negotiated.
+static int gather_layout(mrtx_ctx* c) {
+    if (c->act_version == c->scene_version) return MRTX_OK;
+    c->act_on = false;
+    c->act_slots = c->slots;
+    const bool can = c->cfg.world > 1 && !(c->prm.flags & MRTX_F_NO_CULL) && c->bg == nullptr && c->caps_host.empty();
+    if (can) {
+        c->act_lists.assign((size_t)c->cfg.world, std::vector<int32_t>());
+        int longest = 0;
+        uint64_t px = 0;
+        for (int r = 0; r < c->cfg.world; r++) {
+            cull_tiles(c, r, c->act_lists[(size_t)r], px);
+            longest = std::max(longest, (int)c->act_lists[(size_t)r].size());
+        }
+        if (longest < c->slots) { c->act_on = true; c->act_slots = longest; }
+    }
+    c->act_version = c->scene_version;
+    return MRTX_OK;
+}
+static int upload_layout(mrtx_ctx* c) {
+    if (!c->act_on || c->act_uploaded_version == c->act_version) return MRTX_OK;
+    const size_t n = (size_t)c->cfg.world * (size_t)std::max(1, c->act_slots);
+    std::vector<int32_t> flat(n, -1);
+    for (int r = 0; r < c->cfg.world; r++)
+        std::copy(c->act_lists[(size_t)r].begin(), c->act_lists[(size_t)r].end(), flat.begin() + (size_t)r * (size_t)c->act_slots);
+    if (c->act_dev_cap < n) {
+        if (c->act_dev) { HIPCHK(c, hipFree(c->act_dev)); c->act_dev = nullptr; }
+        HIPCHK(c, hipMalloc((void**)&c->act_dev, n * sizeof(int32_t)));
+        c->act_dev_cap = n;
+    }
+    HIPCHK(c, hipMemcpy(c->act_dev, flat.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->act_uploaded_version = c->act_version;
+    return MRTX_OK;
+}
+static const int32_t* layout_list(const mrtx_ctx* c, int rank) {
+    return c->act_on ? c->act_dev + (size_t)rank * (size_t)c->act_slots : nullptr;
+}
+// root: tiles of other ranks that still hold an earlier view's data and are sky now must read as zero
+static int clear_stale_peer_tiles(mrtx_ctx* c) {
+    if (c->peer_written.size() != (size_t)c->n_tiles) c->peer_written.assign((size_t)c->n_tiles, 0);
+    if (!c->act_on) return MRTX_OK;
+    std::vector<uint8_t> active((size_t)c->n_tiles, 0);
+    for (int r = 0; r < c->cfg.world; r++)
+        for (int32_t lt : c->act_lists[(size_t)r]) active[(size_t)lt * (size_t)c->cfg.world + (size_t)r] = 1;
+    std::vector<int32_t> stale;
+    for (int t = 0; t < c->n_tiles; t++)
+        if (t % c->cfg.world != c->cfg.rank && c->peer_written[(size_t)t] && !active[(size_t)t]) { stale.push_back(t); c->peer_written[(size_t)t] = 0; }
+    if (stale.empty()) return MRTX_OK;
+    if (c->stale_cap < stale.size()) {
+        if (c->stale_dev) { HIPCHK(c, hipFree(c->stale_dev)); c->stale_dev = nullptr; }
+        HIPCHK(c, hipMalloc((void**)&c->stale_dev, (size_t)c->n_tiles * sizeof(int32_t)));
+        c->stale_cap = (size_t)c->n_tiles;
+    }
+    HIPCHK(c, hipMemcpy(c->stale_dev, stale.data(), stale.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, mrtx_launch_zero_tiles(c->accum, c->hits, c->stale_dev, (int)stale.size(), c->cfg.width, c->cfg.height,
+                                     c->cfg.tile_w, c->cfg.tile_h, c->tiles_x, c->tile_shift, c->stream));
+    return MRTX_OK;
+}
+static void mark_peer_written(mrtx_ctx* c, int src_rank) {
+    if (c->peer_written.size() != (size_t)c->n_tiles) c->peer_written.assign((size_t)c->n_tiles, 0);
+    if (c->act_on) {
+        for (int32_t lt : c->act_lists[(size_t)src_rank]) c->peer_written[(size_t)lt * (size_t)c->cfg.world + (size_t)src_rank] = 1;
+    } else {
+        for (int t = src_rank; t < c->n_tiles; t += c->cfg.world) c->peer_written[(size_t)t] = 1;
+    }
+}
+
 int mrtx_shard_bytes(mrtx_ctx* c, int32_t rank, uint64_t* out) {
     if (!c || !out || rank < 0 || rank >= c->cfg.world) return MRTX_E_INVALID;
-    *out = (uint64_t)c->slots * c->cfg.tile_w * c->cfg.tile_h * 32ull;  // equal for every rank (padded)
+    *out = (uint64_t)c->slots * c->cfg.tile_w * c->cfg.tile_h * 32ull;  // equal for every rank (padded): the upper bound
+    return MRTX_OK;
+}
+int mrtx_shard_bytes_active(mrtx_ctx* c, uint64_t* out) {
+    if (!c || !out) return MRTX_E_INVALID;
+    const int rc = gather_layout(c);
+    if (rc != MRTX_OK) return rc;
+    *out = (uint64_t)c->act_slots * c->cfg.tile_w * c->cfg.tile_h * 32ull;
     return MRTX_OK;
 }
 int mrtx_pack_shard(mrtx_ctx* c, void* dev_dst, void* hip_stream) {
     if (!c || !dev_dst) return MRTX_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = gather_layout(c);
+    if (rc == MRTX_OK) rc = upload_layout(c);
+    if (rc != MRTX_OK) return rc;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     HIPCHK(c, mrtx_launch_pack(c->accum, c->hits, dev_dst, c->cfg.width, c->cfg.height, c->cfg.tile_w, c->cfg.tile_h,
-                               c->tiles_x, c->n_tiles, c->cfg.rank, c->cfg.world, c->slots, st));
+                               c->tiles_x, c->n_tiles, c->cfg.rank, c->cfg.world, c->act_slots, layout_list(c, c->cfg.rank), c->tile_shift, st));
     if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
     return MRTX_OK;
 }
 int mrtx_unpack_shard(mrtx_ctx* c, int32_t src_rank, const void* dev_src, void* hip_stream) {
     if (!c || !dev_src || src_rank < 0 || src_rank >= c->cfg.world) return MRTX_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = gather_layout(c);
+    if (rc == MRTX_OK) rc = upload_layout(c);
+    if (rc == MRTX_OK) rc = clear_stale_peer_tiles(c);
+    if (rc != MRTX_OK) return rc;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (hip_stream) HIPCHK(c, hipStreamSynchronize(c->stream));   // the stale-tile clear ran on the context's stream
     HIPCHK(c, mrtx_launch_unpack(c->accum, c->hits, dev_src, c->cfg.width, c->cfg.height, c->cfg.tile_w,
-                                 c->cfg.tile_h, c->tiles_x, c->n_tiles, src_rank, c->cfg.world, c->slots, st));
+                                 c->cfg.tile_h, c->tiles_x, c->n_tiles, src_rank, c->cfg.world, c->act_slots,
+                                 layout_list(c, src_rank), c->tile_shift, st));
+    mark_peer_written(c, src_rank);
     if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
     return MRTX_OK;
 }
@@ -738,10 +847,17 @@ int mrtx_unpack_shard(mrtx_ctx* c, int32_t src_rank, const void* dev_src, void* 
 int mrtx_unpack_all(mrtx_ctx* c, const void* const* dev_srcs, int32_t n) {
     if (!c || !dev_srcs || n != c->cfg.world) return MRTX_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    for (int r = 1; r < n; r++) {
+    int rc = gather_layout(c);
+    if (rc == MRTX_OK) rc = upload_layout(c);
+    if (rc == MRTX_OK) rc = clear_stale_peer_tiles(c);
+    if (rc != MRTX_OK) return rc;
+    for (int r = 0; r < n; r++) {
+        if (r == c->cfg.rank) continue;
         if (!dev_srcs[r]) return fail(c, MRTX_E_INVALID, "missing shard of rank %d", r);
         HIPCHK(c, mrtx_launch_unpack(c->accum, c->hits, dev_srcs[r], c->cfg.width, c->cfg.height, c->cfg.tile_w,
-                                     c->cfg.tile_h, c->tiles_x, c->n_tiles, r, c->cfg.world, c->slots, c->stream));
+                                     c->cfg.tile_h, c->tiles_x, c->n_tiles, r, c->cfg.world, c->act_slots,
+                                     layout_list(c, r), c->tile_shift, c->stream));
+        mark_peer_written(c, r);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MRTX_OK;

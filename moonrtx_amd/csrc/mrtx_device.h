@@ -17,6 +17,27 @@ struct GridC {          // equirectangular grid: row 0 = +90 deg, column 0 = -18
     float row_scale, row_off, col_scale, col_off, wf;
 };
 
+// Tile numbering.  Tile t belongs to rank t % world, and t counts the tiles in raster order with a cyclic shift of
+// `shift` columns per tile row: t = ty * tiles_x + (tx + shift * ty) % tiles_x.  With plain raster numbering and
+// tiles_x a multiple of world (120 columns at 3840 px, world 2/4/8) every rank would own whole tile COLUMNS, which line
+// up with vertical features (the terminator at the default orientation): 12 % rank imbalance at world 8.  The shift
+// -- the smallest odd number >= 3 coprime to world -- turns the ownership into a 2-D lattice.
+static inline __host__ __device__ void mrtx_tile_xy(int t, int tiles_x, int shift, int& tx, int& ty) {
+    ty = t / tiles_x;
+    const int c = t % tiles_x - (int)(((long long)shift * ty) % tiles_x);
+    tx = c < 0 ? c + tiles_x : c;
+}
+static inline __host__ __device__ int mrtx_tile_id(int tx, int ty, int tiles_x, int shift) {
+    return ty * tiles_x + (int)((tx + (long long)shift * ty) % tiles_x);
+}
+static inline int mrtx_tile_shift(int world) {
+    for (int s = 3;; s += 2) {
+        int a = s, b = world;
+        while (b) { const int r = a % b; a = b; b = r; }
+        if (a == 1) return s;
+    }
+}
+
 struct FrameCold {
     // D1 pinhole camera (moon_renderer.py:627-635)
     float Wd[3], Ux[3], Vy[3], two_over_w, two_over_h;
@@ -61,8 +82,11 @@ struct FrameC {
     const FrameCold* cold;  // device memory
     // image-tile sharding (new) + accumulation state
     int32_t tile_w, tile_h, tiles_x, tiles_y, rank, world, n_local_tiles;
+    int32_t tile_shift;         // see mrtx_tile_xy()
     const int32_t* tile_list;   // local tile indices to render (sky tiles culled on the host), or null = all
     int32_t n_active;           // entries of tile_list (== n_local_tiles when null)
+
+    int32_t xcd_share;      // 1: every tile is shared by the 8 XCDs (few tiles per launch), 0: whole tiles per XCD
     uint32_t first_block, n_blocks;
     float* accum;           // W*H float4: running sums r,g,b,coverage
     float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block

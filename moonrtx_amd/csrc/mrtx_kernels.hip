@@ -822,6 +822,12 @@ __device__ __forceinline__ float tree_sum(float v) {
 #ifndef MRTX_MIN_WAVES
 #define MRTX_MIN_WAVES 5   // 93 VGPRs, 5 waves/SIMD, no spill: 4 measures the same, 6 and 8 slower (spills)
 #endif
+#ifndef MRTX_XCD_SHARE
+#define MRTX_XCD_SHARE 1   // 0 = always whole tiles per XCD (A/B switch, see the remap in render_kernel)
+#endif
+#ifndef MRTX_XCD_SHARE_BELOW
+#define MRTX_XCD_SHARE_BELOW 1200   // tiles per launch under which the XCDs share every tile
+#endif
 #ifndef MRTX_MIN_WAVES_BOUNCE
 #define MRTX_MIN_WAVES_BOUNCE 5   // 8 spilled VGPRs at 5 waves/SIMD still beat 4 waves without spills (36.1 vs 39.8 ms)
 #endif
@@ -839,16 +845,28 @@ render_kernel(const FrameC f) {
     __shared__ unsigned int lds_cnt[ST_N];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // XCD-aware remap: consecutive blockIdx values go to XCDs round-robin, so block b and b+8 share
-    // an XCD (and its L2).  Give XCD x the sharding tiles x, x+8, x+16, ... and let it walk the
-    // sub-tiles of one tile back to back.
+    // XCD-aware remap: consecutive blockIdx values go to XCDs round-robin, so block b and b+8 share an XCD (and its
+    // L2).  Two deals, chosen per launch on the host (f.xcd_share):
+    //  0: XCD x gets tiles x, x+8, ... whole -- best L2 locality; 3056 tiles at cfg3 on one GPU average out (14.87 ms
+    //     against 14.99 for the other deal);
+    //  1: every tile is SHARED by the eight XCDs -- XCD x takes the x-th contiguous eighth of its sub-tiles (4 pixel
+    //     rows of a 32x32 tile at S = 64) and all XCDs walk the tile list in step.  Per-tile cost varies ~20x (limb,
+    //     terminator), so a rank holding a few hundred tiles is otherwise bound by its unluckiest XCD: 1/8 of cfg3
+    //     takes 2.24 ms instead of 2.60.
     const int subs_x = f.tile_w >> WGS, subs = subs_x * (f.tile_h >> WGS);
     const int b = blockIdx.x, xcd = b & 7, g = b >> 3;
-    const int li = (g / subs) * 8 + xcd, sub = g % subs;
+    int li, sub;
+    if (f.xcd_share) {
+        const int per = subs >> 3;
+        li = g / per; sub = xcd * per + g % per;
+    } else {
+        li = (g / subs) * 8 + xcd; sub = g % subs;
+    }
     if (li >= f.n_active) return;
     const int lt = f.tile_list ? f.tile_list[li] : li;
     const int t = lt * f.world + f.rank;
-    const int tx = t % f.tiles_x, ty = t / f.tiles_x;
+    int tx, ty;
+    mrtx_tile_xy(t, f.tiles_x, f.tile_shift, tx, ty);
     const int px0 = tx * f.tile_w + (sub % subs_x) * WGT, py0 = ty * f.tile_h + (sub / subs_x) * WGT;
     if (px0 >= f.W || py0 >= f.H) return;
 
@@ -957,18 +975,22 @@ __global__ void resolve_rgba8_kernel(const float4* __restrict__ accum, uint32_t*
 // ------------------------------------------------------------------------------------------------
 // multi-GPU exchange: pack the tiles a rank owns into a dense buffer / scatter a peer's buffer back.
 // Layout of a packed shard: [slot][tile_h][tile_w] float4 sums, then the same for hits; slot k of
-// rank r is tile k*world + r.  Both directions move whole float4 (16 B/lane, coalesced).
+// rank r is local tile k (full layout, list == nullptr) or local tile list[k] (active layout: only tiles the sky
+// cull kept, -1 = padding); local tile lt of rank r is tile lt*world + r.  Whole float4 (16 B/lane, coalesced).
 __global__ void pack_shard_kernel(const float4* __restrict__ accum, const float4* __restrict__ hits,
                                   float4* __restrict__ dst, int W, int H, int tile_w, int tile_h, int tiles_x,
-                                  int n_tiles, int rank, int world, int slots) {
+                                  int n_tiles, int rank, int world, int slots, const int32_t* __restrict__ list, int shift) {
     const int tile_px = tile_w * tile_h;
     const int64_t total = (int64_t)slots * tile_px;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int slot = (int)(i / tile_px), r = (int)(i % tile_px);
-        const int t = slot * world + rank;
+        const int lt = list ? list[slot] : slot;
+        const int t = lt * world + rank;
         float4 a = make_float4(0, 0, 0, 0), h = a;
-        if (t < n_tiles) {
-            const int x = (t % tiles_x) * tile_w + r % tile_w, y = (t / tiles_x) * tile_h + r / tile_w;
+        if (lt >= 0 && t < n_tiles) {
+            int tx, ty;
+            mrtx_tile_xy(t, tiles_x, shift, tx, ty);
+            const int x = tx * tile_w + r % tile_w, y = ty * tile_h + r / tile_w;
             if (x < W && y < H) { a = accum[(int64_t)y * W + x]; h = hits[(int64_t)y * W + x]; }
         }
         dst[i] = a;
@@ -977,15 +999,33 @@ __global__ void pack_shard_kernel(const float4* __restrict__ accum, const float4
 }
 __global__ void unpack_shard_kernel(float4* __restrict__ accum, float4* __restrict__ hits,
                                     const float4* __restrict__ src, int W, int H, int tile_w, int tile_h,
-                                    int tiles_x, int n_tiles, int src_rank, int world, int slots) {
+                                    int tiles_x, int n_tiles, int src_rank, int world, int slots,
+                                    const int32_t* __restrict__ list, int shift) {
     const int tile_px = tile_w * tile_h;
     const int64_t total = (int64_t)slots * tile_px;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int slot = (int)(i / tile_px), r = (int)(i % tile_px);
-        const int t = slot * world + src_rank;
-        if (t >= n_tiles) continue;
-        const int x = (t % tiles_x) * tile_w + r % tile_w, y = (t / tiles_x) * tile_h + r / tile_w;
+        const int lt = list ? list[slot] : slot;
+        const int t = lt * world + src_rank;
+        if (lt < 0 || t >= n_tiles) continue;
+        int tx, ty;
+        mrtx_tile_xy(t, tiles_x, shift, tx, ty);
+        const int x = tx * tile_w + r % tile_w, y = ty * tile_h + r / tile_w;
         if (x < W && y < H) { accum[(int64_t)y * W + x] = src[i]; hits[(int64_t)y * W + x] = src[total + i]; }
+    }
+}
+
+// rank 0, active layout: tiles of other ranks that held data of an earlier view and are sky in this one
+__global__ void zero_tiles_kernel(float4* __restrict__ accum, float4* __restrict__ hits, const int32_t* __restrict__ tiles,
+                                  int n, int W, int H, int tile_w, int tile_h, int tiles_x, int shift) {
+    const int tile_px = tile_w * tile_h;
+    const int64_t total = (int64_t)n * tile_px;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = tiles[i / tile_px], r = (int)(i % tile_px);
+        int tx, ty;
+        mrtx_tile_xy(t, tiles_x, shift, tx, ty);
+        const int x = tx * tile_w + r % tile_w, y = ty * tile_h + r / tile_w;
+        if (x < W && y < H) { accum[(int64_t)y * W + x] = make_float4(0, 0, 0, 0); hits[(int64_t)y * W + x] = make_float4(0, 0, 0, 0); }
     }
 }
 
@@ -1196,11 +1236,13 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, b
     const int wgmin = MRTX_WG_WAVES > 2 ? 2 * PW : MRTX_WG_WAVES > 1 ? 2 * PH : PW;
     const int wgt = (wgmin > MRTX_WG_TILE) ? wgmin : MRTX_WG_TILE;
     const int subs = (f.tile_w / wgt) * (f.tile_h / wgt);
-    const int groups = (f.n_active + 7) / 8;
-    const dim3 grid((unsigned)(groups * subs * 8)), block(64 * MRTX_WG_WAVES);
+    FrameC fr = f;
+    fr.xcd_share = (MRTX_XCD_SHARE && (subs & 7) == 0 && f.n_active < MRTX_XCD_SHARE_BELOW) ? 1 : 0;   // see the remap in render_kernel
+    const int groups = fr.xcd_share ? fr.n_active : (fr.n_active + 7) / 8 * 8;
+    const dim3 grid((unsigned)(groups * subs)), block(64 * MRTX_WG_WAVES);
     if (grid.x == 0) return hipSuccess;
     const bool wide = f.dem_wide != 0;
-#define MRTX_LAUNCH(SV, ST, WD, BN, OV) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, BN, OV>), grid, block, 0, st, f)
+#define MRTX_LAUNCH(SV, ST, WD, BN, OV) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, BN, OV>), grid, block, 0, st, fr)
 #define MRTX_CASE3(SV, BN, OV)                                                                                     \
         if (wide) { if (stats) MRTX_LAUNCH(SV, true, true, BN, OV); else MRTX_LAUNCH(SV, false, true, BN, OV); }   \
         else { if (stats) MRTX_LAUNCH(SV, true, false, BN, OV); else MRTX_LAUNCH(SV, false, false, BN, OV); }
@@ -1247,17 +1289,27 @@ hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t 
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
-                            int tiles_x, int n_tiles, int rank, int world, int slots, hipStream_t st) {
+                            int tiles_x, int n_tiles, int rank, int world, int slots, const int32_t* list, int shift, hipStream_t st) {
+    if (slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(mrtx::pack_shard_kernel, dim3(grid_for((int64_t)slots * tw * th)), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(accum), reinterpret_cast<const float4*>(hits),
-                       reinterpret_cast<float4*>(dst), W, H, tw, th, tiles_x, n_tiles, rank, world, slots);
+                       reinterpret_cast<float4*>(dst), W, H, tw, th, tiles_x, n_tiles, rank, world, slots, list, shift);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
-                              int tiles_x, int n_tiles, int src_rank, int world, int slots, hipStream_t st) {
+                              int tiles_x, int n_tiles, int src_rank, int world, int slots, const int32_t* list, int shift,
+                              hipStream_t st) {
+    if (slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(mrtx::unpack_shard_kernel, dim3(grid_for((int64_t)slots * tw * th)), dim3(256), 0, st,
                        reinterpret_cast<float4*>(accum), reinterpret_cast<float4*>(hits),
-                       reinterpret_cast<const float4*>(src), W, H, tw, th, tiles_x, n_tiles, src_rank, world, slots);
+                       reinterpret_cast<const float4*>(src), W, H, tw, th, tiles_x, n_tiles, src_rank, world, slots, list, shift);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_zero_tiles(float* accum, float* hits, const int32_t* tiles, int n, int W, int H, int tw, int th,
+                                  int tiles_x, int shift, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mrtx::zero_tiles_kernel, dim3(grid_for((int64_t)n * tw * th)), dim3(256), 0, st,
+                       reinterpret_cast<float4*>(accum), reinterpret_cast<float4*>(hits), tiles, n, W, H, tw, th, tiles_x, shift);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_ldem(const int16_t* src, float* dst, int h, int w, int d, unsigned int* max_bits,

@@ -2,9 +2,12 @@
 
 New in this build (the reference is single-GPU): every pixel sample is independent
 given the read-only scene, so the frame is cut into tile_w x tile_h tiles dealt round-robin to ranks
-(tile t -> rank t % world: sky, limb, terminator and night side are spread evenly), each rank renders
+(tile t -> rank t % world, t = raster order with a per-row cyclic shift so ranks form a 2-D lattice: sky, limb,
+terminator and night side are spread evenly -- include/moonrt.h), each rank renders
 its tiles for all samples, and ONE gather brings the packed float4 radiance + hit tiles to rank 0 over
-xGMI (RCCL `gather` = grouped send/recv: every peer uses its own direct link to the root).  No
+xGMI (RCCL `gather` = grouped send/recv: every peer uses its own direct link to the root).  Only tiles the
+sky cull keeps travel (mrtx_shard_bytes_active: ~38 % of a whole-disc 16:9 frame), each rank deriving the layout
+from its own copy of the scene.  No
 reduction is needed -- tiles are disjoint -- and the RNG is keyed by (pixel, sample), so 1-, 2-, 4- and
 8-GPU frames are bit-identical.
 
@@ -20,6 +23,21 @@ def tiles_of(rank, world, width, height, tile=(32, 32)):
     ty = (height + tile[1] - 1) // tile[1]
     n = tx * ty
     return list(range(rank, n, world)), (n + world - 1) // world
+
+
+def tile_shift(world):
+    """Columns of cyclic shift per tile row in the tile numbering (mrtx_tile_shift, csrc/mrtx_device.h)."""
+    import math
+    s = 3
+    while math.gcd(s, world) != 1:
+        s += 2
+    return s
+
+
+def tile_xy(t, tiles_x, shift):
+    """Tile number -> (tx, ty) tile coordinates (mrtx_tile_xy)."""
+    ty, c = divmod(t, tiles_x)
+    return (c - shift * ty) % tiles_x, ty
 
 
 def env_rank_world():
@@ -78,15 +96,21 @@ class FrameGather:
             return
         import torch.distributed as dist
         torch = self.torch
+        n = self.nbytes // 4
+        if hasattr(self.r, "shard_bytes_active"):
+            n = self.r.shard_bytes_active() // 4          # same on every rank: a function of the (identical) scene
+        self.last_bytes = n * 4
         self.r.pack_shard(self.send.data_ptr())          # synchronous on the renderer's stream
-        if self.host_staged:
-            self.send_h.copy_(self.send)
-            dist.gather(self.send_h, self.recv_h if self.rank == 0 else None, dst=0)
+        if n == 0:
+            pass
+        elif self.host_staged:
+            self.send_h[:n].copy_(self.send[:n])
+            dist.gather(self.send_h[:n], [t[:n] for t in self.recv_h] if self.rank == 0 else None, dst=0)
             if self.rank == 0:
                 for src in range(1, self.world):
-                    self.recv[src].copy_(self.recv_h[src])
+                    self.recv[src][:n].copy_(self.recv_h[src][:n])
         else:
-            dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
+            dist.gather(self.send[:n], [t[:n] for t in self.recv] if self.rank == 0 else None, dst=0)
         if self.send.is_cuda:
             torch.cuda.synchronize()
         if self.rank == 0:

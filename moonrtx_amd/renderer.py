@@ -222,6 +222,12 @@ class MoonRT:
                     "mrtx_shard_bytes")
         return n.value
 
+    def shard_bytes_active(self):
+        """Bytes one rank's shard occupies for the scene as it stands (only tiles the sky cull keeps)."""
+        n = C.c_uint64()
+        self._check(self._lib.mrtx_shard_bytes_active(self._ctx, C.byref(n)), "mrtx_shard_bytes_active")
+        return n.value
+
     def pack_shard(self, dev_ptr, stream=None):
         self._check(self._lib.mrtx_pack_shard(self._ctx, dev_ptr, stream), "mrtx_pack_shard")
 

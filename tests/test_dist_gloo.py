@@ -27,7 +27,8 @@ class OracleShardRenderer:
         self.tx = (self.W + TILE[0] - 1) // TILE[0]
 
     def _box(self, t):
-        x0, y0 = (t % self.tx) * TILE[0], (t // self.tx) * TILE[1]
+        tx, ty = mdist.tile_xy(t, self.tx, mdist.tile_shift(self.world))
+        x0, y0 = tx * TILE[0], ty * TILE[1]
         return x0, y0, min(self.W, x0 + TILE[0]), min(self.H, y0 + TILE[1])
 
     def render(self):

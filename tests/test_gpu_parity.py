@@ -303,6 +303,40 @@ def test_sharded_ranks_reassemble_bit_exact(native_lib, dem_small):
             rt.close()
 
 
+def test_gather_moves_only_active_tiles_and_clears_stale_ones(native_lib, dem_small):
+    """The exchange's active layout: only tiles the sky cull keeps travel; after a view change the root's copies of
+    peer tiles that became sky read as zero; with the cull disabled the full layout is used.  All bit-exact."""
+    from dataclasses import replace
+    from moonrtx_amd.renderer import MoonRT, DeviceBuffer
+    from moonrtx_amd import _lib
+    a = named_scene("S1", 192, 96, spp_per_launch=4)                       # disc in the middle of a wide frame
+    b = replace(a, target=(14.0, 0.0, 5.0))                                # disc pushed towards a corner
+    for world in (2, 3):
+        rts = [MoonRT(a.width, a.height, rank=r, world=world, tile=(16, 16)) for r in range(world)]
+        bufs = [DeviceBuffer(rt.shard_bytes()) for rt in rts]
+        for rt in rts:
+            rt.upload_dem(dem_small)
+        for scene, flags in ((a, 0), (b, 0), (a, _lib.F_NO_CULL), (b, 0)):
+            want = MoonRT(a.width, a.height, tile=(16, 16))
+            want.upload_dem(dem_small); want.apply_scene(scene); want.render(1)
+            sizes = []
+            for rt, buf in zip(rts, bufs):
+                rt.apply_scene(scene); rt.set_params(flags=flags); rt.reset(); rt.render(1)
+                sizes.append(rt.shard_bytes_active())
+                rt.pack_shard(buf.ptr)
+            assert len(set(sizes)) == 1
+            if flags == 0:
+                assert 0 < sizes[0] < 0.7 * rts[0].shard_bytes(), (sizes, rts[0].shard_bytes())
+            else:
+                assert sizes[0] == rts[0].shard_bytes()
+            rts[0].unpack_all([buf.ptr for buf in bufs])
+            assert_bit_equal(rts[0].read_linear(), want.read_linear(), f"world={world} radiance")
+            assert_bit_equal(rts[0].read_hits(), want.read_hits(), f"world={world} hits")
+            want.close()
+        for rt in rts:
+            rt.close()
+
+
 def test_rgba8_tonemap_within_one_lsb(native_lib, dem_small):
     s = named_scene("S2", 64, 64, spp_per_launch=4)
     lin, _, _, rgba = render_hip(s, dem_small)

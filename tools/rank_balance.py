@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-rank kernel time of the sharded cfg3 frame, measured one rank after another on ONE GPU: the load balance of the
+tile deal (tile t -> rank t % world) and the bytes each rank would send.  python tools/rank_balance.py [world ...]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import WORKLOADS
+from moonrtx_amd.renderer import MoonRT, synth_ldem, synth_color, dem_from_ldem
+from moonrtx_amd.scene import named_scene
+
+W, H, spp, dem_h, dem_w, col_shape = WORKLOADS["cfg3"]
+src = synth_ldem(dem_h, dem_w, device=0)
+dem_buf, _ = dem_from_ldem(src, dem_h, dem_w, 1, device=0)
+src.free()
+col = synth_color(col_shape[0], col_shape[1], device=0)
+scene = named_scene(os.environ.get("SCENE", "S1"), W, H, spp_per_launch=64)
+for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    ms, nbytes = [], 0
+    for r in range(world):
+        rt = MoonRT(W, H, device=0, rank=r, world=world)
+        rt.bind_dem(dem_buf, dem_h, dem_w)
+        rt.bind_color(col, col_shape[0], col_shape[1])
+        rt.apply_scene(scene)
+        rt.set_params(flags=0)
+        rt.reset(); rt.render(1)
+        t = []
+        for _ in range(3):
+            rt.reset(); t.append(rt.render(1)["kernel_ms"])
+        ms.append(min(t))
+        nbytes = rt.shard_bytes_active() if world > 1 else 0
+        full = rt.shard_bytes()
+        rt.close()
+    print(f"world {world}: kernel ms per rank min {min(ms):.3f} mean {sum(ms) / len(ms):.3f} max {max(ms):.3f} "
+          f"(imbalance {max(ms) / (sum(ms) / len(ms)) - 1:.1%}); sum {sum(ms):.2f}; shard {nbytes / 1e6:.1f} MB active of {full / 1e6:.1f} MB")
