@@ -70,6 +70,7 @@ typedef struct MrtxParams {
 #define MRTX_F_COUNT_STATS 1u  /* maintain the deterministic sample counters of MrtxStats */
 #define MRTX_F_NO_SKIP     4u  /* evaluate every march step (disable the result-preserving max-mip skip) */
 #define MRTX_F_NO_CULL     8u  /* dispatch every tile (disable the host-side sky-tile cull) */
+#define MRTX_F_NO_SORT     16u /* dispatch tiles in raster order (disable the limb-ring-first launch order) */
 #define MRTX_F_FORCE_WIDE  2u  /* test hook: use the 64-bit DEM addressing path (normally only for DEMs > 4 GiB) */
 
 typedef struct MrtxStats {

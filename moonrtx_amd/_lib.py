@@ -37,6 +37,7 @@ F_COUNT_STATS = 1
 F_FORCE_WIDE = 2
 F_NO_SKIP = 4
 F_NO_CULL = 8
+F_NO_SORT = 16
 BUF_ACCUM, BUF_HITS, BUF_DEM, BUF_COLOR = 0, 1, 2, 3
 
 _D3 = C.POINTER(C.c_double)

@@ -326,6 +326,11 @@ void cull_tiles(const mrtx_ctx* c, int rank, std::vector<int32_t>& keep, uint64_
         dp = dp > 1.0 ? 1.0 : (dp < -1.0 ? -1.0 : dp);
         return std::acos(dp);
     };
+    // Longest first: a pixel on the limb marches ~20x longer than one at the disc centre, and a launch ends with its
+    // slowest late wave, so tiles on the limb ring (0.85 .. 1 of the disc's angular radius) go to the FRONT of the
+    // list; raster order is kept inside both classes (neighbouring tiles share DEM lines in L2 / Infinity Cache).
+    std::vector<int32_t> ring;
+    const bool sort_ring = !(c->prm.flags & MRTX_F_NO_SORT) && cones[0].on && !cones[0].all;
     for (int lt = 0; lt < n_local; lt++) {
         const int t = lt * c->cfg.world + rank;
         int ttx, tty;
@@ -344,9 +349,20 @@ void cull_tiles(const mrtx_ctx* c, int rank, std::vector<int32_t>& keep, uint64_
                 if (cones[k].on && ang(d0, cones[k].ax) <= cones[k].half + gamma) need = true;
         }
         if (!need && own && !c->caps_off_host.empty() && c->caps_off_host[(size_t)lt + 1] > c->caps_off_host[(size_t)lt]) need = true;   // overlay tubes here
-        if (need) keep.push_back(lt);
-        else culled_px += (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
+        if (need) {
+            bool on_ring = false;
+            if (sort_ring) {
+                double d0[3];
+                dir(0.5 * (x0 + x1), 0.5 * (y0 + y1), d0);
+                const double rho = ang(d0, cones[0].ax) / cones[0].half;
+                on_ring = rho >= 0.85 && rho <= 1.05;
+            }
+            (on_ring ? ring : keep).push_back(lt);
+        } else {
+            culled_px += (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
+        }
     }
+    keep.insert(keep.begin(), ring.begin(), ring.end());
 }
 
 int check_vec(const double* p) {
@@ -647,7 +663,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
             c->cull_version = c->scene_version;
         }
         culled_px = c->culled_px_cached;
-        culling = (int)c->keep_cached.size() < c->n_local;
+        culling = true;   // the list also carries the launch ORDER, so it is used even when it holds every tile
     }
     const std::vector<int32_t>& keep = c->keep_cached;
     if (culling) {

@@ -20,7 +20,7 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         rt.bind_dem(dem_buf, dem_h, dem_w)
         rt.bind_color(col, col_shape[0], col_shape[1])
         rt.apply_scene(scene)
-        rt.set_params(flags=0)
+        rt.set_params(flags=int(os.environ.get("MRTX_FLAGS", "0")))
         rt.reset(); rt.render(1)
         t = []
         for _ in range(3):
