@@ -148,9 +148,7 @@ def main():
 
     def step():
         rt.reset()
-        st = rt.render(n_blocks)
-        gather.gather()
-        return st
+        return gather.render_and_gather(n_blocks)     # world 1: plain render; world > 1: render in parts, gather overlapped
 
     def barrier():
         if world > 1:

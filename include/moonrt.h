@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRTX_ABI_VERSION 4
+#define MRTX_ABI_VERSION 5
 
 enum {
     MRTX_OK = 0,
@@ -156,6 +156,9 @@ int mrtx_reset_accum(mrtx_ctx* ctx);
  * on_launch_finished callbacks, moon_renderer.py:574; renderer_status.py:239).  Each block adds
  * spp_per_launch samples to every pixel this rank owns.  Blocking.  `out` may be NULL. */
 int mrtx_render(mrtx_ctx* ctx, int32_t n_blocks, MrtxStats* out);
+/* The same block of samples, one part of the tile list at a time (parts 0 .. n_parts-1 in order; the sample counter
+ * advances with the last one), so that the exchange can move part k while part k+1 renders: see mrtx_pack_part. */
+int mrtx_render_part(mrtx_ctx* ctx, int32_t n_blocks, int32_t part, int32_t n_parts, MrtxStats* out);
 
 /* Read-back.  All are full-frame W*H arrays, caller-allocated; on a sharded context pixels of
  * other ranks read as zero.
@@ -180,6 +183,13 @@ int mrtx_shard_bytes(mrtx_ctx* ctx, int32_t rank, uint64_t* out);   /* upper bou
  * pack/unpack below use this layout; a buffer of mrtx_shard_bytes() is always large enough. */
 int mrtx_shard_bytes_active(mrtx_ctx* ctx, uint64_t* out);
 int mrtx_pack_shard(mrtx_ctx* ctx, void* dev_dst, void* hip_stream);
+/* The shard in parts.  A packed shard is [slot][sums tile, hits tile], so a range of slots is one contiguous piece;
+ * part k of n_parts covers the same slot numbers on every rank (the tiles mrtx_render_part(.., k, n_parts) rendered),
+ * is written at byte_off .. byte_off + byte_len of dev_dst, and can be handed to the collective while part k+1
+ * still renders.  mrtx_shard_parts() says how many parts the scene allows (1 while the full layout is in force). */
+int mrtx_shard_parts(mrtx_ctx* ctx, int32_t wanted, int32_t* out);
+int mrtx_pack_part(mrtx_ctx* ctx, void* dev_dst, int32_t part, int32_t n_parts, uint64_t* byte_off, uint64_t* byte_len,
+                   void* hip_stream);
 int mrtx_unpack_shard(mrtx_ctx* ctx, int32_t src_rank, const void* dev_src, void* hip_stream);
 /* Same for every peer at once: dev_srcs[r] is rank r's packed buffer (the own rank's entry is ignored); one
  * synchronisation.  Tiles of peers that held an earlier view's data and are sky in this one are zeroed. */

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOONRT_LIB") or os.path.join(_HERE, "libmoonrt.so")   # MOONRT_LIB: A/B builds only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MrtxConfig(C.Structure):
@@ -64,12 +64,15 @@ SIGNATURES = {
     "mrtx_set_capsules": (C.c_int, [_VP, _VP, C.c_int32]),
     "mrtx_reset_accum": (C.c_int, [_VP]),
     "mrtx_render": (C.c_int, [_VP, C.c_int32, C.POINTER(MrtxStats)]),
+    "mrtx_render_part": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(MrtxStats)]),
     "mrtx_read_linear": (C.c_int, [_VP, _VP]),
     "mrtx_read_rgba8": (C.c_int, [_VP, _VP]),
     "mrtx_read_hits": (C.c_int, [_VP, _VP]),
     "mrtx_samples_done": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
     "mrtx_shard_bytes": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64)]),
     "mrtx_shard_bytes_active": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    "mrtx_shard_parts": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_int32)]),
+    "mrtx_pack_part": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _VP]),
     "mrtx_pack_shard": (C.c_int, [_VP, _VP, _VP]),
     "mrtx_unpack_shard": (C.c_int, [_VP, C.c_int32, _VP, _VP]),
     "mrtx_unpack_all": (C.c_int, [_VP, C.POINTER(_VP), C.c_int32]),

@@ -21,7 +21,8 @@ hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t np
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
                                      float invg, const uint32_t* overlay, hipStream_t st);
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
-                            int tiles_x, int n_tiles, int rank, int world, int slots, const int32_t* list, int shift, hipStream_t st);
+                            int tiles_x, int n_tiles, int rank, int world, int slot0, int slots, const int32_t* list, int shift,
+                            hipStream_t st);
 hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
                               int tiles_x, int n_tiles, int src_rank, int world, int slots, const int32_t* list, int shift,
                               hipStream_t st);
@@ -629,9 +630,20 @@ int mrtx_reset_accum(mrtx_ctx* c) {
     return MRTX_OK;
 }
 
-int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
+static int gather_layout(mrtx_ctx* c);
+// slots [a, b) of part `part` of `n_parts` over n entries: contiguous, sizes differ by at most one
+static void part_range(int n, int part, int n_parts, int& a, int& b) {
+    a = (int)((int64_t)n * part / n_parts);
+    b = (int)((int64_t)n * (part + 1) / n_parts);
+}
+
+int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) { return mrtx_render_part(c, n_blocks, 0, 1, out); }
+
+int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_parts, MrtxStats* out) {
     if (!c) return MRTX_E_INVALID;
     if (n_blocks < 1) return fail(c, MRTX_E_INVALID, "n_blocks must be >= 1");
+    if (n_parts < 1 || part < 0 || part >= n_parts) return fail(c, MRTX_E_INVALID, "bad part %d of %d", part, n_parts);
+    if (n_parts > 1 && (c->prm.flags & MRTX_F_NO_CULL)) return fail(c, MRTX_E_STATE, "parts need the tile list (MRTX_F_NO_CULL is set)");
     if (!c->dem) return fail(c, MRTX_E_STATE, "no displacement map: call mrtx_upload_dem first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (!(c->prm.flags & MRTX_F_NO_SKIP)) { const int rc_ = ensure_mip(c); if (rc_ != MRTX_OK) return rc_; }
@@ -674,8 +686,16 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
             }
             c->keep_uploaded = keep;
         }
-        f.tile_list = c->tile_list_dev;
-        f.n_active = (int)keep.size();
+        int pa = 0, pb = (int)keep.size();
+        if (n_parts > 1) {   // cut where the shard parts cut: at slot numbers of the COMMON (longest) list
+            const int rc_ = gather_layout(c);
+            if (rc_ != MRTX_OK) return rc_;
+            if (!c->act_on) return fail(c, MRTX_E_STATE, "parts need the active gather layout (mrtx_shard_parts)");
+            part_range(c->act_slots, part, n_parts, pa, pb);
+            pa = std::min(pa, (int)keep.size()); pb = std::min(pb, (int)keep.size());
+        }
+        f.tile_list = c->tile_list_dev + pa;
+        f.n_active = pb - pa;
         // culled tiles are all-zero by construction: clear only if an earlier view rendered into one of them
         std::vector<uint8_t> kept((size_t)c->n_local, 0);
         for (int32_t lt : keep) kept[(size_t)lt] = 1;
@@ -697,7 +717,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
     HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->prm.path_seg_max > 1, overlay, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->blocks_done += (uint32_t)n_blocks;
+    if (part == n_parts - 1) c->blocks_done += (uint32_t)n_blocks;
     if (out) {
         std::memset(out, 0, sizeof *out);
         float ms = 0.0f;
@@ -707,7 +727,7 @@ int mrtx_render(mrtx_ctx* c, int32_t n_blocks, MrtxStats* out) {
         if (stats) {
             unsigned long long h[16];
             HIPCHK(c, hipMemcpy(h, c->stats_dev, sizeof h, hipMemcpyDeviceToHost));
-            out->primary_rays = h[0] + culled_px * (uint64_t)c->prm.spp_per_launch * (uint64_t)n_blocks;
+            out->primary_rays = h[0] + (part == 0 ? culled_px : 0) * (uint64_t)c->prm.spp_per_launch * (uint64_t)n_blocks;
             out->primary_hits = h[1]; out->shadow_rays = h[2];
             out->height_samples = h[3]; out->colour_fetches = h[4]; out->background_fetches = h[5];
             out->dem_fetches = h[6]; out->mip_fetches = h[7]; out->bounce_rays = h[8];
@@ -831,16 +851,38 @@ int mrtx_shard_bytes_active(mrtx_ctx* c, uint64_t* out) {
     *out = (uint64_t)c->act_slots * c->cfg.tile_w * c->cfg.tile_h * 32ull;
     return MRTX_OK;
 }
-int mrtx_pack_shard(mrtx_ctx* c, void* dev_dst, void* hip_stream) {
-    if (!c || !dev_dst) return MRTX_E_INVALID;
+int mrtx_pack_shard(mrtx_ctx* c, void* dev_dst, void* hip_stream) { return mrtx_pack_part(c, dev_dst, 0, 1, nullptr, nullptr, hip_stream); }
+
+// Part `part` of `n_parts` of the shard: the slots whose tiles mrtx_render_part(.., part, n_parts) rendered (own
+// tiles first come first; the padding up to the common slot count goes with the last part).
+int mrtx_pack_part(mrtx_ctx* c, void* dev_dst, int32_t part, int32_t n_parts, uint64_t* byte_off, uint64_t* byte_len,
+                   void* hip_stream) {
+    if (!c || !dev_dst || n_parts < 1 || part < 0 || part >= n_parts) return MRTX_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc = gather_layout(c);
     if (rc == MRTX_OK) rc = upload_layout(c);
     if (rc != MRTX_OK) return rc;
+    if (n_parts > 1 && !c->act_on) return fail(c, MRTX_E_STATE, "the shard moves in parts only in the active layout (mrtx_shard_parts)");
+    // every rank cuts at the SAME slot numbers (parts of the longest list), so part k of every peer lands at one offset
+    int a, b;
+    part_range(c->act_slots, part, n_parts, a, b);
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     HIPCHK(c, mrtx_launch_pack(c->accum, c->hits, dev_dst, c->cfg.width, c->cfg.height, c->cfg.tile_w, c->cfg.tile_h,
-                               c->tiles_x, c->n_tiles, c->cfg.rank, c->cfg.world, c->act_slots, layout_list(c, c->cfg.rank), c->tile_shift, st));
+                               c->tiles_x, c->n_tiles, c->cfg.rank, c->cfg.world, a, b - a, layout_list(c, c->cfg.rank),
+                               c->tile_shift, st));
+    const uint64_t slot_bytes = (uint64_t)c->cfg.tile_w * c->cfg.tile_h * 32ull;
+    if (byte_off) *byte_off = (uint64_t)a * slot_bytes;
+    if (byte_len) *byte_len = (uint64_t)(b - a) * slot_bytes;
     if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
+    return MRTX_OK;
+}
+// How many parts the exchange may use for the scene as it stands (1 when the full layout is in force), and which
+// render part produces the tiles of shard part k: shard parts cut the COMMON slot range, render parts must cover them.
+int mrtx_shard_parts(mrtx_ctx* c, int32_t wanted, int32_t* out) {
+    if (!c || !out || wanted < 1) return MRTX_E_INVALID;
+    const int rc = gather_layout(c);
+    if (rc != MRTX_OK) return rc;
+    *out = (c->act_on && c->act_slots >= wanted) ? wanted : 1;
     return MRTX_OK;
 }
 int mrtx_unpack_shard(mrtx_ctx* c, int32_t src_rank, const void* dev_src, void* hip_stream) {

@@ -974,16 +974,18 @@ __global__ void resolve_rgba8_kernel(const float4* __restrict__ accum, uint32_t*
 
 // ------------------------------------------------------------------------------------------------
 // multi-GPU exchange: pack the tiles a rank owns into a dense buffer / scatter a peer's buffer back.
-// Layout of a packed shard: [slot][tile_h][tile_w] float4 sums, then the same for hits; slot k of
+// Layout of a packed shard: per slot one tile of float4 sums followed by one tile of float4 hits (so any range of slots
+// is one contiguous piece: the exchange moves the shard in parts while later parts still render); slot k of
 // rank r is local tile k (full layout, list == nullptr) or local tile list[k] (active layout: only tiles the sky
 // cull kept, -1 = padding); local tile lt of rank r is tile lt*world + r.  Whole float4 (16 B/lane, coalesced).
 __global__ void pack_shard_kernel(const float4* __restrict__ accum, const float4* __restrict__ hits,
                                   float4* __restrict__ dst, int W, int H, int tile_w, int tile_h, int tiles_x,
-                                  int n_tiles, int rank, int world, int slots, const int32_t* __restrict__ list, int shift) {
+                                  int n_tiles, int rank, int world, int slot0, int slots, const int32_t* __restrict__ list,
+                                  int shift) {
     const int tile_px = tile_w * tile_h;
     const int64_t total = (int64_t)slots * tile_px;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int slot = (int)(i / tile_px), r = (int)(i % tile_px);
+        const int slot = slot0 + (int)(i / tile_px), r = (int)(i % tile_px);
         const int lt = list ? list[slot] : slot;
         const int t = lt * world + rank;
         float4 a = make_float4(0, 0, 0, 0), h = a;
@@ -993,8 +995,9 @@ __global__ void pack_shard_kernel(const float4* __restrict__ accum, const float4
             const int x = tx * tile_w + r % tile_w, y = ty * tile_h + r / tile_w;
             if (x < W && y < H) { a = accum[(int64_t)y * W + x]; h = hits[(int64_t)y * W + x]; }
         }
-        dst[i] = a;
-        dst[total + i] = h;
+        const int64_t o = (int64_t)slot * 2 * tile_px + r;
+        dst[o] = a;
+        dst[o + tile_px] = h;
     }
 }
 __global__ void unpack_shard_kernel(float4* __restrict__ accum, float4* __restrict__ hits,
@@ -1011,7 +1014,8 @@ __global__ void unpack_shard_kernel(float4* __restrict__ accum, float4* __restri
         int tx, ty;
         mrtx_tile_xy(t, tiles_x, shift, tx, ty);
         const int x = tx * tile_w + r % tile_w, y = ty * tile_h + r / tile_w;
-        if (x < W && y < H) { accum[(int64_t)y * W + x] = src[i]; hits[(int64_t)y * W + x] = src[total + i]; }
+        const int64_t o = (int64_t)slot * 2 * tile_px + r;
+        if (x < W && y < H) { accum[(int64_t)y * W + x] = src[o]; hits[(int64_t)y * W + x] = src[o + tile_px]; }
     }
 }
 
@@ -1289,11 +1293,12 @@ hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t 
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
-                            int tiles_x, int n_tiles, int rank, int world, int slots, const int32_t* list, int shift, hipStream_t st) {
+                            int tiles_x, int n_tiles, int rank, int world, int slot0, int slots, const int32_t* list, int shift,
+                            hipStream_t st) {
     if (slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(mrtx::pack_shard_kernel, dim3(grid_for((int64_t)slots * tw * th)), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(accum), reinterpret_cast<const float4*>(hits),
-                       reinterpret_cast<float4*>(dst), W, H, tw, th, tiles_x, n_tiles, rank, world, slots, list, shift);
+                       reinterpret_cast<float4*>(dst), W, H, tw, th, tiles_x, n_tiles, rank, world, slot0, slots, list, shift);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,

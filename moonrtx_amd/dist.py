@@ -90,6 +90,41 @@ class FrameGather:
             self.send_h = torch.empty(self.nbytes // 4, dtype=torch.float32, pin_memory=True)
             self.recv_h = [torch.empty(self.nbytes // 4, dtype=torch.float32) for _ in range(self.world)] if self.rank == 0 else None
 
+    def render_and_gather(self, n_blocks=1, parts=None):
+        """One block of samples on every rank + the exchange, overlapped: the tile list renders in `parts` pieces
+        (default MOONRT_GATHER_PARTS or 2) and the RCCL gather of piece k runs on the collective's stream while
+        piece k+1 renders.  Falls back to render() + gather() when the scene needs the full layout, on a single
+        rank, and with host-staged (gloo) transport.  Returns the summed render statistics."""
+        r = self.r
+        if parts is None:
+            parts = int(os.environ.get("MOONRT_GATHER_PARTS", "2"))
+        P = r.shard_parts(parts) if (self.world > 1 and parts > 1 and hasattr(r, "shard_parts") and not self.host_staged) else 1
+        if P == 1:
+            st = r.render(n_blocks)
+            self.gather()
+            return st
+        import torch.distributed as dist
+        works, total = [], None
+        for k in range(P):
+            st = r.render_part(n_blocks, k, P)                      # returns when the piece is rendered
+            off, ln = r.pack_part(self.send.data_ptr(), k, P)       # synchronous on the renderer's stream
+            a, b = off // 4, (off + ln) // 4
+            if b > a:                                               # same cut on every rank
+                works.append(dist.gather(self.send[a:b], [t[a:b] for t in self.recv] if self.rank == 0 else None,
+                                         dst=0, async_op=True))
+            if total is None:
+                total = dict(st)
+            else:
+                for key, v in st.items():
+                    total[key] += v
+        for w in works:
+            w.wait()
+        self.torch.cuda.synchronize()
+        self.last_bytes = r.shard_bytes_active()
+        if self.rank == 0:
+            r.unpack_all([t.data_ptr() for t in self.recv])
+        return total
+
     def gather(self):
         """After every rank has rendered: bring all tiles to rank 0's framebuffer."""
         if self.world == 1:

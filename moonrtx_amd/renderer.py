@@ -195,6 +195,12 @@ class MoonRT:
         self._check(self._lib.mrtx_render(self._ctx, int(n_blocks), C.byref(st)), "mrtx_render")
         return {name: getattr(st, name) for name, _ in MrtxStats._fields_ if name != "reserved"}
 
+    def render_part(self, n_blocks, part, n_parts):
+        """One part of the tile list (mrtx_render_part): the exchange moves part k while part k+1 renders."""
+        st = MrtxStats()
+        self._check(self._lib.mrtx_render_part(self._ctx, int(n_blocks), int(part), int(n_parts), C.byref(st)), "mrtx_render_part")
+        return {name: getattr(st, name) for name, _ in MrtxStats._fields_ if name != "reserved"}
+
     def samples_done(self):
         n = C.c_uint32()
         self._check(self._lib.mrtx_samples_done(self._ctx, C.byref(n)), "mrtx_samples_done")
@@ -227,6 +233,18 @@ class MoonRT:
         n = C.c_uint64()
         self._check(self._lib.mrtx_shard_bytes_active(self._ctx, C.byref(n)), "mrtx_shard_bytes_active")
         return n.value
+
+    def shard_parts(self, wanted):
+        n = C.c_int32()
+        self._check(self._lib.mrtx_shard_parts(self._ctx, int(wanted), C.byref(n)), "mrtx_shard_parts")
+        return n.value
+
+    def pack_part(self, dev_ptr, part, n_parts, stream=None):
+        """Pack part `part` of the shard; returns (byte offset, byte length) of the piece inside the shard buffer."""
+        off, ln = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.mrtx_pack_part(self._ctx, dev_ptr, int(part), int(n_parts), C.byref(off), C.byref(ln), stream),
+                    "mrtx_pack_part")
+        return off.value, ln.value
 
     def pack_shard(self, dev_ptr, stream=None):
         self._check(self._lib.mrtx_pack_shard(self._ctx, dev_ptr, stream), "mrtx_pack_shard")

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound(native_lib):
 
 def test_abi_version_and_struct_layouts(native_lib):
     from moonrtx_amd import _lib
-    assert native_lib.mrtx_abi_version() == 4
+    assert native_lib.mrtx_abi_version() == 5
     assert C.sizeof(_lib.MrtxConfig) == 28
     assert C.sizeof(_lib.MrtxParams) == 56
     assert C.sizeof(_lib.MrtxStats) == 88

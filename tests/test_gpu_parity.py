@@ -332,9 +332,57 @@ def test_gather_moves_only_active_tiles_and_clears_stale_ones(native_lib, dem_sm
             rts[0].unpack_all([buf.ptr for buf in bufs])
             assert_bit_equal(rts[0].read_linear(), want.read_linear(), f"world={world} radiance")
             assert_bit_equal(rts[0].read_hits(), want.read_hits(), f"world={world} hits")
+            # the same exchange in parts (what FrameGather.render_and_gather overlaps with rendering)
+            for P in (2, 3):
+                if flags != 0:
+                    assert rts[0].shard_parts(P) == 1            # full layout: no parts
+                    continue
+                assert rts[0].shard_parts(P) == P
+                pieces = []
+                for rt, buf in zip(rts, bufs):
+                    rt.reset()
+                    buf.upload(np.zeros(buf.nbytes, np.uint8))
+                    cover = []
+                    for k in range(P):
+                        rt.render_part(1, k, P)
+                        cover.append(rt.pack_part(buf.ptr, k, P))
+                    assert rt.samples_done() == scene.spp_per_launch
+                    pieces.append(cover)
+                assert all(p == pieces[0] for p in pieces)        # every rank cuts at the same bytes
+                assert pieces[0][0][0] == 0 and sum(ln for _, ln in pieces[0]) == sizes[0]
+                assert all(pieces[0][k][0] + pieces[0][k][1] == pieces[0][k + 1][0] for k in range(P - 1))
+                rts[0].unpack_all([buf.ptr for buf in bufs])
+                assert_bit_equal(rts[0].read_linear(), want.read_linear(), f"world={world} parts={P} radiance")
+                assert_bit_equal(rts[0].read_hits(), want.read_hits(), f"world={world} parts={P} hits")
             want.close()
         for rt in rts:
             rt.close()
+
+
+_RCCL_SNIPPET = r"""
+import os, sys, tempfile, torch, torch.distributed as dist
+with tempfile.TemporaryDirectory() as d:
+    dist.init_process_group("nccl", init_method="file://" + os.path.join(d, "store"), rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    send = torch.arange(4096, dtype=torch.float32, device="cuda")
+    recv = [torch.zeros_like(send)]
+    works = [dist.gather(send[a:b], [t[a:b] for t in recv], dst=0, async_op=True) for a, b in ((0, 1000), (1000, 4096))]
+    for w in works:
+        w.wait()
+    torch.cuda.synchronize()
+    ok = torch.equal(recv[0], send)
+    dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def test_rccl_async_gather_of_views():
+    """The collective calls FrameGather.render_and_gather() makes -- async gathers of slices of one buffer into slices of
+    the receive buffers -- on the real RCCL backend (one rank is all a one-GPU box can host).  Own process: torch
+    must bring up its HIP runtime before anything else touches the device, as in bench.py."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "-c", _RCCL_SNIPPET], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 def test_rgba8_tonemap_within_one_lsb(native_lib, dem_small):
