@@ -207,8 +207,12 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     f.dem = c->dem; k.color = c->color; k.bg = c->bg;
     f.mip = c->mip; f.mip_pitch = c->mip_w + 2; f.mip_h = c->mip_h; f.mip_w = c->mip_w; f.mip_shift = c->mip_shift;
     f.dem_pitch = c->dem_w + 4;
+#if MRTX_DEM_PAIRS
+    f.dem_maxidx = (uint32_t)((uint64_t)(c->dem_h + 4) * (uint64_t)(c->dem_w + 4) - 2);   // elements idx and idx+1 are read
+#else
     f.dem_maxidx = (uint32_t)((uint64_t)(c->dem_h + 2) * (uint64_t)(c->dem_w + 4) + (uint64_t)(c->dem_w + 2));
-    f.dem_wide = ((uint64_t)(c->dem_h + 4) * (uint64_t)(c->dem_w + 4) * 4ull > 0xFFFFFFFFull) ? 1 : 0;
+#endif
+    f.dem_wide = ((uint64_t)(c->dem_h + 4) * (uint64_t)(c->dem_w + 4) * MRTX_DEM_ELEM_BYTES > 0xFFFFFFFFull) ? 1 : 0;
     f.tile_w = c->cfg.tile_w; f.tile_h = c->cfg.tile_h;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.tile_shift = c->tile_shift;
     f.rank = c->cfg.rank; f.world = c->cfg.world; f.n_local_tiles = c->n_local;
@@ -463,7 +467,7 @@ const char* mrtx_last_error(mrtx_ctx* c) { return c ? c->err.c_str() : "null con
 static int ingest_dem(mrtx_ctx* c, const float* dev_src, int32_t h, int32_t w) {
     if (c->dem) { HIPCHK(c, hipFree(c->dem)); }
     c->dem = nullptr; c->dem_h = c->dem_w = 0;
-    const size_t bytes = (size_t)(h + 4) * (size_t)(w + 4) * sizeof(float);
+    const size_t bytes = (size_t)(h + 4) * (size_t)(w + 4) * MRTX_DEM_ELEM_BYTES;
     HIPCHK(c, hipMalloc((void**)&c->dem, bytes));
     HIPCHK(c, mrtx_launch_pad_dem(dev_src, c->dem, h, w, c->stream));
     if (c->mip) { HIPCHK(c, hipFree(c->mip)); }
@@ -927,7 +931,7 @@ int mrtx_device_ptr(mrtx_ctx* c, int32_t which, void** out, uint64_t* bytes) {
     switch (which) {
         case MRTX_BUF_ACCUM: *out = c->accum; if (bytes) *bytes = fb; break;
         case MRTX_BUF_HITS: *out = c->hits; if (bytes) *bytes = fb; break;
-        case MRTX_BUF_DEM: *out = c->dem; if (bytes) *bytes = c->dem ? (uint64_t)(c->dem_h + 4) * (c->dem_w + 4) * 4 : 0; break;
+        case MRTX_BUF_DEM: *out = c->dem; if (bytes) *bytes = c->dem ? (uint64_t)(c->dem_h + 4) * (c->dem_w + 4) * MRTX_DEM_ELEM_BYTES : 0; break;
         case MRTX_BUF_COLOR: *out = c->color; if (bytes) *bytes = (uint64_t)c->color_h * c->color_w * 4; break;
         default: return fail(c, MRTX_E_INVALID, "unknown buffer id %d", which);
     }

@@ -17,6 +17,13 @@ struct GridC {          // equirectangular grid: row 0 = +90 deg, column 0 = -18
     float row_scale, row_off, col_scale, col_off, wf;
 };
 
+// DEM layout in HBM (see dem_march() in mrtx_kernels.hip): 1 = row pairs, element (r, c) = float2 (D[r][c], D[r+1][c]),
+// so the 2x2 footprint of a bilinear evaluation is ONE 16-byte load; 0 = plain padded float32, two 8-byte loads.
+#ifndef MRTX_DEM_PAIRS
+#define MRTX_DEM_PAIRS 1
+#endif
+#define MRTX_DEM_ELEM_BYTES (MRTX_DEM_PAIRS ? 8 : 4)
+
 // Tile numbering.  Tile t belongs to rank t % world, and t counts the tiles in raster order with a cyclic shift of
 // `shift` columns per tile row: t = ty * tiles_x + (tx + shift * ty) % tiles_x.  With plain raster numbering and
 // tiles_x a multiple of world (120 columns at 3840 px, world 2/4/8) every rank would own whole tile COLUMNS, which line

@@ -142,6 +142,7 @@ __device__ __forceinline__ float lerp2(float e00, float e01, float e10, float e1
 // path, where floor() lands in [-1,h-1] x [-1,w-1], and one texel either side of it for the normal -- is two
 // unconditional 8-byte loads: no clamp, no wrap, no seam branch.
 struct __attribute__((packed, aligned(4))) Pair { float x, y; };
+struct __attribute__((packed, aligned(8))) Quad { float a, b, c, d; };
 
 template <bool WIDE>
 __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float colf) {
@@ -152,6 +153,14 @@ __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float co
     const uint32_t r0p = (uint32_t)((int)rfl + 2), c0p = (uint32_t)((int)cfl + 2);
     const uint32_t idx = min(__umul24(r0p, (uint32_t)f.dem_pitch) + c0p, f.dem_maxidx);
     const char* base = reinterpret_cast<const char*>(f.dem);
+#if MRTX_DEM_PAIRS
+    // row-pair layout: element (r, c) = (D[r][c], D[r+1][c]); elements (r0, c0) and (r0, c0+1) are adjacent, so the
+    // whole 2x2 footprint is ONE 16-byte load -- half the gather instructions and L1 tag look-ups of two row loads
+    Quad q;
+    if (WIDE) q = *reinterpret_cast<const Quad*>(base + ((uint64_t)idx << 3));
+    else q = *reinterpret_cast<const Quad*>(base + (idx << 3));
+    return lerp2(q.a, q.c, q.b, q.d, fr, fc);
+#else
     Pair t, u;
     if (WIDE) {
         const char* p = base + ((uint64_t)idx << 2);
@@ -163,6 +172,7 @@ __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float co
         u = *reinterpret_cast<const Pair*>(base + off1);
     }
     return lerp2(t.x, t.y, u.x, u.y, fr, fc);
+#endif
 }
 
 struct Tap {
@@ -772,7 +782,16 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         if (STATS) cnt[ST_BOUNCE]++;
         Seg bsg;
         float bhi = 0.0f;
-        if (!march<WIDE, false, STATS, BATCH>(f, boa, bob, boc, bda, bdb, bdc, 0.0f, bsg, bhi, cnt)) {
+#if defined(MRTX_EXP_BOUNCE) && MRTX_EXP_BOUNCE == 2      // timing experiment: no bounce march at all
+        bool bhit = false;
+#else
+        bool bhit = march<WIDE, false, STATS, BATCH>(f, boa, bob, boc, bda, bdb, bdc, 0.0f, bsg, bhi, cnt);
+#endif
+#if defined(MRTX_EXP_BOUNCE) && MRTX_EXP_BOUNCE == 1      // timing experiment: march, then pretend it escaped
+        asm volatile("" :: "v"((int)bhit), "v"(bhi));
+        bhit = false;
+#endif
+        if (!bhit) {
             if (CF(f)->bg) {   // the path leaves the Moon: environment radiance along its direction (scene frame)
                 const float ex = fmaf(bdc, CF(f)->Mf[2][0], fmaf(bdb, CF(f)->Mf[1][0], bda * CF(f)->Mf[0][0]));
                 const float ey = fmaf(bdc, CF(f)->Mf[2][1], fmaf(bdb, CF(f)->Mf[1][1], bda * CF(f)->Mf[0][1]));
@@ -1188,9 +1207,15 @@ __global__ void pad_dem_kernel(const float* __restrict__ src, float* __restrict_
     const int64_t n = (int64_t)(h + 4) * pitch;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int r = (int)(i / pitch) - 2, c = (int)(i % pitch) - 2;
+        const int r1 = r + 1 < 0 ? 0 : (r + 1 > h - 1 ? h - 1 : r + 1);
         r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
         c = c < 0 ? c + w : (c > w - 1 ? c - w : c);
+#if MRTX_DEM_PAIRS
+        reinterpret_cast<float2*>(dst)[i] = make_float2(src[(int64_t)r * w + c], src[(int64_t)r1 * w + c]);
+#else
+        (void)r1;
         dst[i] = src[(int64_t)r * w + c];
+#endif
     }
 }
 
@@ -1221,8 +1246,8 @@ __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, in
         const int c0 = max(C * j - 2, -2), c1 = min(C * j + C + 1, w + 1);
         float m = 0.0f;
         for (int r = r0; r <= r1; r++) {
-            const float* row = dem_padded + (int64_t)(r + 2) * pitch + 2;
-            for (int c = c0; c <= c1; c++) m = fmaxf(m, row[c]);
+            const float* row = dem_padded + ((int64_t)(r + 2) * pitch + 2) * (MRTX_DEM_ELEM_BYTES / 4);
+            for (int c = c0; c <= c1; c++) m = fmaxf(m, row[c * (MRTX_DEM_ELEM_BYTES / 4)]);
         }
         mip[t] = m;
     }

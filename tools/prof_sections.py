@@ -17,6 +17,8 @@ dem_buf, _ = dem_from_ldem(src, dem_h, dem_w, 1, device=0)
 src.free()
 col = synth_color(col_shape[0], col_shape[1], device=0)
 scene = named_scene(sc, W, H, spp_per_launch=64)
+if os.environ.get("PATH_SEG"):
+    scene.path_seg_min, scene.path_seg_max = [int(t) for t in os.environ["PATH_SEG"].split(",")]
 rt = MoonRT(W, H, device=0)
 rt.bind_dem(dem_buf, dem_h, dem_w)
 rt.bind_color(col, col_shape[0], col_shape[1])
