@@ -36,6 +36,7 @@ hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float*
                                     hipStream_t st);
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st);
 hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, int shift, hipStream_t st);
+hipError_t mrtx_launch_mip_pairs(const float* mip, float* out_pairs, int rows, int pitch, hipStream_t st);
 hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out, hipStream_t st);
 
 struct mrtx_ctx {
@@ -488,8 +489,15 @@ static int ensure_mip(mrtx_ctx* c) {
     c->mip = nullptr;
     const int cell = 1 << shift;
     c->mip_h = (c->dem_h + cell - 1) / cell; c->mip_w = (c->dem_w + cell - 1) / cell;
-    HIPCHK(c, hipMalloc((void**)&c->mip, (size_t)(c->mip_h + 2) * (c->mip_w + 2) * sizeof(float)));
-    HIPCHK(c, mrtx_launch_mip(c->dem, c->dem_h, c->dem_w, c->mip, c->mip_h, c->mip_w, shift, c->stream));
+    const size_t cells = (size_t)(c->mip_h + 2) * (c->mip_w + 2);
+    float* plain = nullptr;
+    HIPCHK(c, hipMalloc((void**)&plain, cells * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&c->mip, (cells + 1) * 2 * sizeof(float));   // row pairs + one element of slack for the 16-byte load
+    if (e == hipSuccess) e = mrtx_launch_mip(c->dem, c->dem_h, c->dem_w, plain, c->mip_h, c->mip_w, shift, c->stream);
+    if (e == hipSuccess) e = mrtx_launch_mip_pairs(plain, c->mip, c->mip_h + 2, c->mip_w + 2, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(plain);
+    HIPCHK(c, e);
     c->mip_shift = shift;
     return MRTX_OK;
 }

@@ -259,9 +259,12 @@ __device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, f
         const bool usable = !sg.exact & (i1 - i0 <= 1) & (j1 - j0 <= 1) & (i0 >= -1) & (i1 <= f.mip_h) & (j0 >= -1) &
                             (j1 <= f.mip_w);
         if (usable) {
-            const float* __restrict__ m = f.mip;
-            const int ra = (i0 + 1) * f.mip_pitch, rb = (i1 + 1) * f.mip_pitch;
-            const float dmax = fmaxf(fmaxf(m[ra + j0 + 1], m[ra + j1 + 1]), fmaxf(m[rb + j0 + 1], m[rb + j1 + 1]));
+            // the mip is stored in row pairs as well (element (i, j) = (m[i][j], m[i+1][j])): one 16-byte load brings the
+            // 2x2 cells at (i0, j0); the ones the footprint does not reach are ignored, so the bound is the old one
+            const Quad q = *reinterpret_cast<const Quad*>(reinterpret_cast<const char*>(f.mip) +
+                                                          ((uint32_t)((i0 + 1) * f.mip_pitch + j0 + 1) << 3));
+            const bool two_r = i1 > i0, two_c = j1 > j0;
+            const float dmax = fmaxf(fmaxf(q.a, two_r ? q.b : q.a), fmaxf(two_c ? q.c : q.a, (two_r & two_c) ? q.d : q.a));
             if (STATS) cnt[ST_MIP] += 4;
             const float rd = f.Rf * dmax;
             const float T = (rd * rd) * 1.00001f;
@@ -1253,6 +1256,15 @@ __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, in
     }
 }
 
+// plain max-mip (mh+2) x (mw+2) -> row pairs: element (i, j) = (m[i][j], m[i+1][j]), the last row paired with itself
+__global__ void mip_pair_kernel(const float* __restrict__ mip, float2* __restrict__ out, int rows, int pitch) {
+    const int n = rows * pitch;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int r = t / pitch;
+        out[t] = make_float2(mip[t], mip[r + 1 < rows ? t + pitch : t]);
+    }
+}
+
 }  // namespace mrtx
 
 // ------------------------------------------------------------------------------------------------
@@ -1373,6 +1385,11 @@ hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out
 hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, int shift, hipStream_t st) {
     hipLaunchKernelGGL(mrtx::mip_build_kernel, dim3(grid_for((int64_t)(mh + 2) * (mw + 2))), dim3(64), 0, st, dem_padded,
                        h, w, mip, mh, mw, shift);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_mip_pairs(const float* mip, float* out_pairs, int rows, int pitch, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::mip_pair_kernel, dim3(grid_for((int64_t)rows * pitch)), dim3(256), 0, st, mip,
+                       reinterpret_cast<float2*>(out_pairs), rows, pitch);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st) {
