@@ -197,7 +197,9 @@ int mrtx_unpack_all(mrtx_ctx* ctx, const void* const* dev_srcs, int32_t n);
 
 /* Raw device pointers of the context's buffers (for zero-copy wrapping by the host side). */
 /* MRTX_BUF_DEM is the context's own copy of the displacement map in its march layout: (h+4) x (w+4) elements of
- * float2 (D[r][c], D[r+1][c]), two-texel border (rows clamp, columns wrap) -- not the array that was uploaded. */
+ * float2 (D[r][c], D[r+1][c]), two-texel border (rows clamp, columns wrap) -- not the array that was uploaded.
+ * MRTX_BUF_COLOR likewise: (h+1) x (w+4) elements of two RGBA8 texels (T[r][c], T[r+1][c]).  mrtx_bind_dem_device and
+ * mrtx_bind_color_device read the caller's device array once; the caller may free it afterwards. */
 enum { MRTX_BUF_ACCUM = 0, MRTX_BUF_HITS = 1, MRTX_BUF_DEM = 2, MRTX_BUF_COLOR = 3 };
 int mrtx_device_ptr(mrtx_ctx* ctx, int32_t which, void** out, uint64_t* bytes);
 

@@ -36,6 +36,7 @@ hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float*
                                     hipStream_t st);
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st);
 hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, int shift, hipStream_t st);
+hipError_t mrtx_launch_color_pairs(const uint32_t* src, void* dst, int h, int w, hipStream_t st);
 hipError_t mrtx_launch_mip_pairs(const float* mip, float* out_pairs, int rows, int pitch, hipStream_t st);
 hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out, hipStream_t st);
 
@@ -453,7 +454,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->stale_dev) (void)hipFree(c->stale_dev);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
-    if (c->color && c->color_owned) (void)hipFree(c->color);
+    if (c->color) (void)hipFree(c->color);
     if (c->bg) (void)hipFree(c->bg);
     if (c->overlay) (void)hipFree(c->overlay);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -520,28 +521,38 @@ int mrtx_bind_dem_device(mrtx_ctx* c, const void* dev, int32_t h, int32_t w) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     return ingest_dem(c, (const float*)dev, h, w);
 }
+// The context keeps the colour map in ROW PAIRS (color_pair_kernel): 8 bytes per texel, (h+1) x (w+4) elements + slack.
+static int ingest_color(mrtx_ctx* c, const void* dev_src, int32_t h, int32_t w) {
+    if (c->color) { HIPCHK(c, hipFree(c->color)); }
+    c->color = nullptr; c->color_h = c->color_w = 0;
+    if (!dev_src) return MRTX_OK;
+    const size_t elems = (size_t)(h + 1) * (size_t)(w + 4) + 1;
+    HIPCHK(c, hipMalloc((void**)&c->color, elems * 8));
+    HIPCHK(c, mrtx_launch_color_pairs((const uint32_t*)dev_src, c->color, h, w, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->color_h = h; c->color_w = w;
+    return MRTX_OK;
+}
 int mrtx_upload_color(mrtx_ctx* c, const uint8_t* rgba, int32_t h, int32_t w) {
     if (!c) return MRTX_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->color && c->color_owned) { HIPCHK(c, hipFree(c->color)); }
-    c->color = nullptr; c->color_owned = false; c->color_h = c->color_w = 0;
-    if (!rgba) return MRTX_OK;
+    if (!rgba) return ingest_color(c, nullptr, 0, 0);
     if (h < 2 || w < 2) return fail(c, MRTX_E_INVALID, "colour texture must be (h>=2, w>=2, 4) uint8");
     const size_t bytes = (size_t)h * w * 4;
-    HIPCHK(c, hipMalloc((void**)&c->color, bytes));
-    c->color_owned = true;
-    HIPCHK(c, hipMemcpy(c->color, rgba, bytes, hipMemcpyHostToDevice));
-    c->color_h = h; c->color_w = w;
-    return MRTX_OK;
+    void* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, bytes));
+    hipError_t e = hipMemcpy(tmp, rgba, bytes, hipMemcpyHostToDevice);
+    int rc = MRTX_OK;
+    if (e == hipSuccess) rc = ingest_color(c, tmp, h, w);
+    (void)hipFree(tmp);
+    HIPCHK(c, e);
+    return rc;
 }
 int mrtx_bind_color_device(mrtx_ctx* c, const void* dev, int32_t h, int32_t w) {
     if (!c) return MRTX_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->color && c->color_owned) { HIPCHK(c, hipFree(c->color)); }
-    c->color = (uint8_t*)dev; c->color_owned = false;
-    c->color_h = dev ? h : 0; c->color_w = dev ? w : 0;
-    if (dev && (h < 2 || w < 2)) { c->color = nullptr; return fail(c, MRTX_E_INVALID, "bad device colour texture"); }
-    return MRTX_OK;
+    if (dev && (h < 2 || w < 2)) return fail(c, MRTX_E_INVALID, "bad device colour texture");
+    return ingest_color(c, dev, h, w);   // the caller's buffer is read once; the context keeps its own row-pair copy
 }
 int mrtx_upload_background(mrtx_ctx* c, const uint8_t* rgba, int32_t h, int32_t w) {
     if (!c) return MRTX_E_INVALID;
@@ -940,7 +951,7 @@ int mrtx_device_ptr(mrtx_ctx* c, int32_t which, void** out, uint64_t* bytes) {
         case MRTX_BUF_ACCUM: *out = c->accum; if (bytes) *bytes = fb; break;
         case MRTX_BUF_HITS: *out = c->hits; if (bytes) *bytes = fb; break;
         case MRTX_BUF_DEM: *out = c->dem; if (bytes) *bytes = c->dem ? (uint64_t)(c->dem_h + 4) * (c->dem_w + 4) * MRTX_DEM_ELEM_BYTES : 0; break;
-        case MRTX_BUF_COLOR: *out = c->color; if (bytes) *bytes = (uint64_t)c->color_h * c->color_w * 4; break;
+        case MRTX_BUF_COLOR: *out = c->color; if (bytes) *bytes = c->color ? ((uint64_t)(c->color_h + 1) * (c->color_w + 4) + 1) * 8 : 0; break;
         default: return fail(c, MRTX_E_INVALID, "unknown buffer id %d", which);
     }
     return MRTX_OK;

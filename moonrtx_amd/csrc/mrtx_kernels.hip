@@ -143,6 +143,7 @@ __device__ __forceinline__ float lerp2(float e00, float e01, float e10, float e1
 // unconditional 8-byte loads: no clamp, no wrap, no seam branch.
 struct __attribute__((packed, aligned(4))) Pair { float x, y; };
 struct __attribute__((packed, aligned(8))) Quad { float a, b, c, d; };
+struct __attribute__((packed, aligned(8))) UQuad { uint32_t a, b, c, d; };
 
 template <bool WIDE>
 __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float colf) {
@@ -175,30 +176,12 @@ __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float co
 #endif
 }
 
-struct Tap {
-    int32_t ra, rb, ca, cb;
-    float fr, fc;
-};
 __device__ __forceinline__ int32_t wrapc(int32_t c, int32_t w) {
     if (c < 0) c += w;
     if (c >= w) c -= w;
     if (c < 0) c += w;
     if (c >= w) c -= w;
     return c;
-}
-// general form (normal estimation one texel either side of the hit; colour texture)
-__device__ __forceinline__ Tap grid_tap(const GridC& g, float rowf, float colf) {
-    const float rfl = floorf(rowf), cfl = floorf(colf);
-    int32_t r0 = (int32_t)rfl, c0 = (int32_t)cfl;
-    r0 = r0 < -1 ? -1 : (r0 > g.h - 1 ? g.h - 1 : r0);
-    c0 = c0 < -2 ? -2 : (c0 > g.w ? g.w : c0);
-    Tap t;
-    t.ra = r0 < 0 ? 0 : r0;
-    t.rb = r0 + 1 > g.h - 1 ? g.h - 1 : r0 + 1;
-    t.ca = wrapc(c0, g.w);
-    t.cb = wrapc(c0 + 1, g.w);
-    t.fr = rowf - rfl; t.fc = colf - cfl;
-    return t;
 }
 // ---- D2/D3: the march.
 // Texel coordinates are smooth along a ray, while the exact (lat, lon) -> (row, col) costs ~65 VALU (sqrt,
@@ -509,15 +492,21 @@ __device__ __forceinline__ void hit_vertex(const FrameC& f, float ha, float hb, 
         GridC gcl;   // scalar-load the colour grid constants (member-wise: no copy constructor across address spaces)
         gcl.h = CF(f)->gc.h; gcl.w = CF(f)->gc.w; gcl.row_scale = CF(f)->gc.row_scale; gcl.row_off = CF(f)->gc.row_off;
         gcl.col_scale = CF(f)->gc.col_scale; gcl.col_off = CF(f)->gc.col_off; gcl.wf = CF(f)->gc.wf;
-        const Tap t = grid_tap(gcl, rc, cc);
-        const uint32_t* tex = reinterpret_cast<const uint32_t*>(CF(f)->color);
-        const int64_t ra = (int64_t)t.ra * CF(f)->gc.w, rb = (int64_t)t.rb * CF(f)->gc.w;
-        const uint32_t p00 = tex[ra + t.ca], p01 = tex[ra + t.cb], p10 = tex[rb + t.ca], p11 = tex[rb + t.cb];
-        v.al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), t.fr, t.fc) * kInv255;
+        // row-pair layout as for the DEM (color_pair_kernel): element (r, c) = (T[max(r,0)][wrap(c)], T[min(r+1,h-1)][wrap(c)])
+        // for r in [-1, h-1], c in [-2, w+1]: the 2x2 RGBA8 footprint is one 16-byte load instead of four gathers
+        const float rfl = floorf(rc), cfl = floorf(cc);
+        int32_t r0 = (int32_t)rfl, c0 = (int32_t)cfl;
+        r0 = r0 < -1 ? -1 : (r0 > gcl.h - 1 ? gcl.h - 1 : r0);
+        c0 = c0 < -2 ? -2 : (c0 > gcl.w ? gcl.w : c0);
+        const float tfr = rc - rfl, tfc = cc - cfl;
+        const uint64_t ci = (uint64_t)(uint32_t)(r0 + 1) * (uint64_t)(uint32_t)(gcl.w + 4) + (uint64_t)(uint32_t)(c0 + 2);
+        const UQuad cq = *reinterpret_cast<const UQuad*>(reinterpret_cast<const char*>(CF(f)->color) + (ci << 3));
+        const uint32_t p00 = cq.a, p10 = cq.b, p01 = cq.c, p11 = cq.d;
+        v.al0 = lerp2((float)(p00 & 255u), (float)(p01 & 255u), (float)(p10 & 255u), (float)(p11 & 255u), tfr, tfc) * kInv255;
         v.al1 = lerp2((float)((p00 >> 8) & 255u), (float)((p01 >> 8) & 255u), (float)((p10 >> 8) & 255u),
-                      (float)((p11 >> 8) & 255u), t.fr, t.fc) * kInv255;
+                      (float)((p11 >> 8) & 255u), tfr, tfc) * kInv255;
         v.al2 = lerp2((float)((p00 >> 16) & 255u), (float)((p01 >> 16) & 255u), (float)((p10 >> 16) & 255u),
-                      (float)((p11 >> 16) & 255u), t.fr, t.fc) * kInv255;
+                      (float)((p11 >> 16) & 255u), tfr, tfc) * kInv255;
         if (STATS) cnt[ST_COLOUR]++;
     } else {
         v.al0 = CF(f)->const_albedo[0]; v.al1 = CF(f)->const_albedo[1]; v.al2 = CF(f)->const_albedo[2];
@@ -1222,6 +1211,19 @@ __global__ void pad_dem_kernel(const float* __restrict__ src, float* __restrict_
     }
 }
 
+// colour map (h, w) RGBA8 -> row pairs (h+1, w+4): element (r, c) = (T[max(r,0)][wrap(c)], T[min(r+1,h-1)][wrap(c)]) for
+// r in [-1, h-1], c in [-2, w+1] -- exactly the taps the bilinear colour fetch of hit_vertex() defines
+__global__ void color_pair_kernel(const uint32_t* __restrict__ src, uint2* __restrict__ dst, int h, int w) {
+    const int pitch = w + 4;
+    const int64_t n = (int64_t)(h + 1) * pitch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / pitch) - 1;
+        const int c = wrapc((int)(i % pitch) - 2, w);
+        const int ra = r < 0 ? 0 : r, rb = r + 1 > h - 1 ? h - 1 : r + 1;
+        dst[i] = make_uint2(src[(int64_t)ra * w + c], src[(int64_t)rb * w + c]);
+    }
+}
+
 // FETCH_SIZE calibration (MI355X_MICROARCH.md, HBM section): stream a buffer once with this kernel's own access width
 // (one 8-byte load per lane) so the PMC reading can be compared with a known byte count.
 __global__ void probe_stream_kernel(const Pair* __restrict__ src, int64_t n_pairs, float* __restrict__ out) {
@@ -1390,6 +1392,11 @@ hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, in
 hipError_t mrtx_launch_mip_pairs(const float* mip, float* out_pairs, int rows, int pitch, hipStream_t st) {
     hipLaunchKernelGGL(mrtx::mip_pair_kernel, dim3(grid_for((int64_t)rows * pitch)), dim3(256), 0, st, mip,
                        reinterpret_cast<float2*>(out_pairs), rows, pitch);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_color_pairs(const uint32_t* src, void* dst, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::color_pair_kernel, dim3(grid_for((int64_t)(h + 1) * (w + 4))), dim3(256), 0, st, src,
+                       reinterpret_cast<uint2*>(dst), h, w);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipStream_t st) {
