@@ -420,6 +420,23 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
     return hit;
 }
 
+// D3 refinement: nbis bisections of (lo, hi) on below().  (Two levels per round -- the three mid-points evaluated
+// together, 3 dependent rounds instead of 5 -- measured no faster: 13.90 vs 13.85 ms.)
+template <bool WIDE>
+__device__ __forceinline__ void refine(const FrameC& f, const Seg& sg, float oa, float ob, float oc, float da, float db,
+                                       float dc, float& lo, float& hi) {
+    auto below = [&](float s) {
+        const float ma = fmaf(s, da, oa), mb = fmaf(s, db, ob), mc = fmaf(s, dc, oc);
+        return below_seg<WIDE, true>(f, sg, s, ma, mb, mc, fmaf(mc, mc, fmaf(mb, mb, ma * ma)));
+    };
+    for (int i = 0; i < f.nbis; i++) {
+        const float mid = 0.5f * (lo + hi);
+        const bool bel = below(mid);
+        hi = bel ? mid : hi;
+        lo = bel ? lo : mid;
+    }
+}
+
 struct Vertex {
     float pa, pb, pc;      // surface point (moon frame)
     float na, nb, nc;      // unit normal
@@ -682,13 +699,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
             // hi = (float)k * step of the first sample below; k recovered exactly (|k*step/step - k| << 0.5)
             const int k = (int)rintf(hi * f.inv_step);
             lo = (float)(k - 1) * f.step;
-            for (int i = 0; i < f.nbis; i++) {
-                const float mid = 0.5f * (lo + hi);
-                const float ma = fmaf(mid, da, pa), mb = fmaf(mid, db, pb), mc = fmaf(mid, dc, pc);
-                const bool bel = below_seg<WIDE, true>(f, sg, mid, ma, mb, mc, fmaf(mc, mc, fmaf(mb, mb, ma * ma)));
-                hi = bel ? mid : hi;
-                lo = bel ? lo : mid;
-            }
+            refine<WIDE>(f, sg, pa, pb, pc, da, db, dc, lo, hi);
             if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
         }
         PROF_END(3);
@@ -798,13 +809,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         }
         const int bk = (int)rintf(bhi * f.inv_step);
         float blo = (float)(bk - 1) * f.step;
-        for (int i = 0; i < f.nbis; i++) {
-            const float mid = 0.5f * (blo + bhi);
-            const float ma = fmaf(mid, bda, boa), mb = fmaf(mid, bdb, bob), mc = fmaf(mid, bdc, boc);
-            const bool bel = below_seg<WIDE, true>(f, bsg, mid, ma, mb, mc, fmaf(mc, mc, fmaf(mb, mb, ma * ma)));
-            bhi = bel ? mid : bhi;
-            blo = bel ? blo : mid;
-        }
+        refine<WIDE>(f, bsg, boa, bob, boc, bda, bdb, bdc, blo, bhi);
         if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
         hit_vertex<STATS, WIDE>(f, fmaf(blo, bda, boa), fmaf(blo, bdb, bob), fmaf(blo, bdc, boc), v, cnt);
         seg++;
