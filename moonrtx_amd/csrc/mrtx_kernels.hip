@@ -388,6 +388,14 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
     rq.b = fmaf(oc, dc, fmaf(ob, db, oa * da));
     rq.a = fmaf(dc, dc, fmaf(db, db, da * da));
     bool hit = false, go = true;
+    if (!PRIMARY) {
+        // The skip below relies on "once outside, always outside".  r^2(s) is convex, so that holds from the first
+        // step that is inside -- but an origin lifted by scene_epsilon off a D = 1 texel can sit just outside R and head
+        // inward: the march ends at step 1 (spec), and must not resume where the parabola dips back inside.
+        const float s1 = f.step;
+        const float pa = fmaf(s1, da, oa), pb = fmaf(s1, db, ob), pc = fmaf(s1, dc, oc);
+        go = fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f;
+    }
     int ka = 0;
     while (go) {
         float rowB, colB, q2B;

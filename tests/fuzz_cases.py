@@ -1,0 +1,123 @@
+"""Random parity cases (tests/test_gpu_fuzz.py, tools/fuzz_parity.py).
+
+Every case draws a DEM (size, relief, roughness), an optional colour map / environment map, a camera (whole disc,
+close-up, oblique, limb-grazing, any roll), field of view, light, Sun disc, march step / epsilons, samples per launch,
+path length, frame size (not a multiple of the tile), tile size and flags (wide addressing, no skip, no cull, no sort),
+to be rendered through libmoonrt.so and through oracle/mrtx_oracle.c and compared bit for bit (radiance, hit records,
+spec counters).  Test infrastructure."""
+import math
+
+import numpy as np
+
+from moonrtx_amd import _lib
+from moonrtx_amd.scene import named_scene
+
+
+def random_dem(rng):
+    h = int(rng.choice([8, 24, 90, 180, 360]))
+    w = 2 * h if rng.random() < 0.8 else int(h * rng.uniform(1.3, 3.0))
+    relief = float(rng.choice([0.002, 0.012, 0.05, 0.12]))
+    kind = rng.integers(0, 3)
+    if kind == 0:                                   # white noise
+        d = rng.random((h, w))
+    elif kind == 1:                                 # smooth: low-pass noise
+        d = rng.random((h, w))
+        for _ in range(3):
+            d = 0.25 * (np.roll(d, 1, 0) + np.roll(d, -1, 0) + np.roll(d, 1, 1) + np.roll(d, -1, 1))
+        d = (d - d.min()) / max(1e-9, d.max() - d.min())
+    else:                                           # terraces and spikes
+        d = np.floor(rng.random((h, w)) * 4) / 4.0
+        d[rng.integers(0, h), rng.integers(0, w)] = 1.0
+    d = (1.0 - relief + relief * d).astype(np.float32)
+    d.flat[rng.integers(0, d.size)] = 1.0           # peak exactly 1.0, as load_elevation_data guarantees
+    return d
+
+
+def random_scene(rng):
+    W = int(rng.integers(17, 150)); H = int(rng.integers(13, 110))
+    S = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+    s = named_scene(str(rng.choice(["S1", "S2", "S3"])), W, H, spp_per_launch=S,
+                    libration=(float(rng.uniform(-180, 180)), float(rng.uniform(-90, 90))), seed=int(rng.integers(1, 1 << 30)))
+    R = s.radius
+    mode = rng.integers(0, 5)
+    d = np.array([rng.normal(), rng.normal(), rng.normal()]); d /= np.linalg.norm(d)
+    if mode == 0:                                   # whole disc from a random direction
+        s.eye = tuple(d * R * rng.uniform(8, 40)); s.target = (0.0, 0.0, 0.0)
+        s.vfov_deg = float(np.degrees(2 * math.atan(R / 0.9 / np.linalg.norm(s.eye))) * rng.uniform(0.6, 1.6))
+    elif mode == 1:                                 # close-up of a surface point
+        p = d * R
+        s.eye = tuple(p * rng.uniform(1.02, 1.6) + np.cross(d, [0.3, 0.5, 0.8]) * R * rng.uniform(0, 0.3)); s.target = tuple(p)
+        s.vfov_deg = float(rng.uniform(2, 50))
+    elif mode == 2:                                 # limb-grazing: look past the edge
+        t = np.cross(d, [0.1, 0.9, 0.4]); t /= np.linalg.norm(t)
+        s.eye = tuple(d * R * rng.uniform(1.05, 3.0)); s.target = tuple(np.array(s.eye) + t * R - d * R * rng.uniform(0.0, 0.4))
+        s.vfov_deg = float(rng.uniform(5, 70))
+    elif mode == 3:                                 # default camera, zoomed / shifted
+        s.target = tuple(rng.uniform(-R, R, 3) * 0.7); s.vfov_deg = float(rng.uniform(0.3, 8))
+    else:                                           # mostly sky
+        s.target = tuple(d * R * rng.uniform(1.5, 4)); s.vfov_deg = float(rng.uniform(1, 20))
+    up = np.array([rng.normal(), rng.normal(), rng.normal()])
+    w = np.array(s.target) - np.array(s.eye)
+    if np.linalg.norm(np.cross(w, up)) < 1e-3 * np.linalg.norm(w) * np.linalg.norm(up):
+        up = np.array([0.0, 0.0, 1.0])
+    s.up = tuple(up)
+    ld = np.array([rng.normal(), rng.normal(), rng.normal()]); ld /= np.linalg.norm(ld)
+    s.light_pos = tuple(ld * 21460.0); s.light_radius = float(rng.choice([0.0 + 1e-3, 50.0, 100.0, 900.0]))
+    if rng.random() < 0.5:
+        s.sun_pos = tuple(np.array(s.eye) + (np.array(s.target) - np.array(s.eye)) / np.linalg.norm(w) * 3100.0 + rng.normal(size=3) * 60.0)
+        s.sun_radius = float(rng.uniform(5, 60))
+    s.marching_step = float(rng.choice([5e-3, 2e-3, 1.3e-2, 3e-2]))
+    s.marching_step_eps = float(s.marching_step * rng.choice([0.06, 0.2, 0.5]))
+    s.scene_epsilon = float(rng.choice([1e-4, 0.0, 1e-3]))
+    if rng.random() < 0.45:
+        s.path_seg_min = int(rng.integers(1, 4)); s.path_seg_max = int(rng.integers(s.path_seg_min, 5))
+    if rng.random() < 0.3:
+        k = float(rng.uniform(0.2, 3.0)); off = rng.uniform(-5, 5, 3)
+        s.radius = R * k; s.center = tuple(off)
+        for name in ("eye", "target"):
+            setattr(s, name, tuple(off + k * np.array(getattr(s, name))))
+        s.light_pos = tuple(off + np.array(s.light_pos)); s.sun_pos = tuple(off + np.array(s.sun_pos))
+        s.marching_step *= k; s.marching_step_eps *= k; s.scene_epsilon *= k
+        s.sun_radius *= 1.0
+    return s
+
+
+
+
+def cases(seed):
+    """Endless generator of (description, dem, colour, background, scene, flags, tile, blocks)."""
+    rng = np.random.default_rng(seed)
+    case = 0
+    while True:
+        dem = random_dem(rng)
+        col = (rng.integers(0, 256, (int(rng.integers(2, 40)), int(rng.integers(2, 70)), 4), dtype=np.uint8)
+               if rng.random() < 0.6 else None)
+        bg = (rng.integers(0, 256, (int(rng.integers(1, 20)), int(rng.integers(1, 40)), 4), dtype=np.uint8)
+              if rng.random() < 0.3 else None)
+        s = random_scene(rng)
+        flags = _lib.F_COUNT_STATS
+        for f, p in ((_lib.F_FORCE_WIDE, 0.3), (_lib.F_NO_SKIP, 0.15), (_lib.F_NO_CULL, 0.15), (_lib.F_NO_SORT, 0.15)):
+            if rng.random() < p:
+                flags |= f
+        tile = tuple(int(t) for t in rng.choice([16, 32, 48], 2))
+        blocks = (1,) if rng.random() < 0.7 else (1, 2)
+        desc = (f"seed {seed} case {case}: dem {dem.shape} frame {s.width}x{s.height} S={s.spp_per_launch} "
+                f"seg=({s.path_seg_min},{s.path_seg_max}) fov {s.vfov_deg:.2f} step {s.marching_step:.2g} flags {flags} tile {tile} "
+                f"blocks {blocks} col {None if col is None else col.shape[:2]} bg {None if bg is None else bg.shape[:2]}")
+        yield desc, dem, col, bg, s, flags, tile, blocks
+        case += 1
+
+
+def check_case(c):
+    """Render one case on both sides and compare bit for bit; returns the oracle's statistics."""
+    from common import STAT_KEYS, assert_bit_equal, render_hip, render_oracle
+    desc, dem, col, bg, s, flags, tile, blocks = c
+    lin_h, hits_h, st_h, _ = render_hip(s, dem, col, bg, blocks=blocks, tile=tile, flags=flags)
+    lin_o, hits_o, st_o = render_oracle(s, dem, col, bg, blocks=blocks)
+    assert_bit_equal(lin_h, lin_o, desc + ": radiance")
+    assert_bit_equal(hits_h, hits_o, desc + ": hits")
+    if len(blocks) == 1:
+        got = {k: st_h[k] for k in STAT_KEYS}
+        want = {k: st_o[k] for k in STAT_KEYS}
+        assert got == want, f"{desc}: counters {got} vs {want}"
+    return st_o
