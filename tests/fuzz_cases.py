@@ -85,7 +85,8 @@ def random_scene(rng):
 
 
 def cases(seed):
-    """Endless generator of (description, dem, colour, background, scene, flags, tile, blocks)."""
+    """Endless generator of (description, dem, colour, background, scene, flags, tile, blocks, extra); `extra` =
+    dict(capsules, world, parts) drawn from a second stream, so case k of a seed keeps its scene as options are added."""
     rng = np.random.default_rng(seed)
     case = 0
     while True:
@@ -101,19 +102,76 @@ def cases(seed):
                 flags |= f
         tile = tuple(int(t) for t in rng.choice([16, 32, 48], 2))
         blocks = (1,) if rng.random() < 0.7 else (1, 2)
+        rng2 = np.random.default_rng([seed, case, 77])
+        capsules = None
+        if rng2.random() < 0.25:                    # overlay tubes outside the bounding sphere (D11)
+            n = int(rng2.integers(1, 12))
+            caps = np.zeros((n, 12), np.float32)
+            ctr = np.asarray(s.center, float)
+            for i in range(n):
+                a = rng2.normal(size=3); a /= np.linalg.norm(a)
+                b = a + rng2.normal(size=3) * rng2.uniform(0.02, 0.8); b /= np.linalg.norm(b)
+                caps[i, 0:3] = ctr + a * s.radius * rng2.uniform(1.02, 1.3)
+                caps[i, 4:7] = ctr + b * s.radius * rng2.uniform(1.02, 1.3)
+                caps[i, 3] = s.radius * rng2.uniform(0.001, 0.03)
+                caps[i, 8:11] = rng2.random(3)
+            capsules = caps
+        extra = dict(capsules=capsules, world=int(rng2.choice([1, 1, 2, 3])), parts=int(rng2.choice([1, 2, 3])))
+        if rng2.random() < 0.12:                    # camera INSIDE the bounding sphere: low orbit, or under the terrain
+            e = rng2.normal(size=3); e /= np.linalg.norm(e)
+            s.eye = tuple(np.asarray(s.center, float) + e * s.radius * rng2.uniform(0.85, 0.9999))
+            t = rng2.normal(size=3); t /= np.linalg.norm(t)
+            s.target = tuple(np.asarray(s.eye) + t * s.radius)
+            s.up = tuple(np.cross(t, [0.37, 0.11, 0.92])); s.vfov_deg = float(rng2.uniform(10, 120))
         desc = (f"seed {seed} case {case}: dem {dem.shape} frame {s.width}x{s.height} S={s.spp_per_launch} "
                 f"seg=({s.path_seg_min},{s.path_seg_max}) fov {s.vfov_deg:.2f} step {s.marching_step:.2g} flags {flags} tile {tile} "
-                f"blocks {blocks} col {None if col is None else col.shape[:2]} bg {None if bg is None else bg.shape[:2]}")
-        yield desc, dem, col, bg, s, flags, tile, blocks
+                f"blocks {blocks} col {None if col is None else col.shape[:2]} bg {None if bg is None else bg.shape[:2]} "
+                f"caps {0 if capsules is None else len(capsules)} world {extra['world']} parts {extra['parts']}")
+        yield desc, dem, col, bg, s, flags, tile, blocks, extra
         case += 1
+
+
+def render_sharded(s, dem, col, bg, blocks, tile, flags, capsules, world, parts):
+    """`world` contexts on one GPU: every rank renders its tiles (in `parts` pieces when the layout allows), rank 0
+    unpacks the peers' shards -- the exchange of FrameGather without the collective."""
+    from moonrtx_amd.renderer import DeviceBuffer, MoonRT
+    rts = [MoonRT(s.width, s.height, rank=r, world=world, tile=tile) for r in range(world)]
+    bufs = [DeviceBuffer(rt.shard_bytes()) for rt in rts]
+    try:
+        for rt in rts:
+            rt.upload_dem(dem); rt.upload_color(col); rt.upload_background(bg)
+            rt.apply_scene(s); rt.set_capsules(capsules); rt.set_params(flags=flags)
+        for nb in blocks:
+            for rt, buf in zip(rts, bufs):
+                P = rt.shard_parts(parts) if not (flags & _lib.F_NO_CULL) else 1
+                if P > 1:
+                    for k in range(P):
+                        rt.render_part(nb, k, P)
+                        rt.pack_part(buf.ptr, k, P)
+                else:
+                    rt.render(nb)
+                    rt.pack_shard(buf.ptr)
+            rts[0].unpack_all([b.ptr for b in bufs])
+        return rts[0].read_linear(), rts[0].read_hits()
+    finally:
+        for rt in rts:
+            rt.close()
+        for b in bufs:
+            b.free()
 
 
 def check_case(c):
     """Render one case on both sides and compare bit for bit; returns the oracle's statistics."""
     from common import STAT_KEYS, assert_bit_equal, render_hip, render_oracle
-    desc, dem, col, bg, s, flags, tile, blocks = c
-    lin_h, hits_h, st_h, _ = render_hip(s, dem, col, bg, blocks=blocks, tile=tile, flags=flags)
-    lin_o, hits_o, st_o = render_oracle(s, dem, col, bg, blocks=blocks)
+    desc, dem, col, bg, s, flags, tile, blocks, extra = c
+    caps = extra["capsules"]
+    lin_o, hits_o, st_o = render_oracle(s, dem, col, bg, blocks=blocks, capsules=caps)
+    if extra["world"] > 1:
+        lin_h, hits_h = render_sharded(s, dem, col, bg, blocks, tile, flags, caps, extra["world"], extra["parts"])
+        assert_bit_equal(lin_h, lin_o, desc + ": sharded radiance")
+        assert_bit_equal(hits_h, hits_o, desc + ": sharded hits")
+        return st_o
+    lin_h, hits_h, st_h, _ = render_hip(s, dem, col, bg, blocks=blocks, tile=tile, flags=flags, capsules=caps)
     assert_bit_equal(lin_h, lin_o, desc + ": radiance")
     assert_bit_equal(hits_h, hits_o, desc + ": hits")
     if len(blocks) == 1:
