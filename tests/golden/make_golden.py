@@ -12,6 +12,7 @@ import numpy as np
 
 sys.path.insert(0, "/root/reference")
 from moonrtx.renderer_navigation import NavigationMixin  # noqa: E402
+from moonrtx import moon_grid  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -107,5 +108,27 @@ def main():
     print("golden vectors written to", HERE)
 
 
+
+def grid_graphs():
+    """4. The overlay graphs MoonRTX hands to set_graph (renderer_labels.py:172-177, :291-300): grid lines and grid
+    labels from moon_grid.create_moon_grid() + merge_segments_to_graph().  Stored as data: vertex / edge arrays."""
+    g = moon_grid.create_moon_grid()
+    lines_pos, lines_edges = moon_grid.merge_segments_to_graph(g.lat_lines + g.lon_lines)
+    segs = [seg for segs in g.lat_labels for seg in segs] + [seg for segs in g.lon_labels for seg in segs] + list(g.N)
+    labels_pos, labels_edges = moon_grid.merge_segments_to_graph(segs)
+    np.savez_compressed(os.path.join(HERE, "moon_grid_graphs.npz"),
+                        lines_pos=np.asarray(lines_pos, np.float32), lines_edges=np.asarray(lines_edges, np.int32),
+                        labels_pos=np.asarray(labels_pos, np.float32), labels_edges=np.asarray(labels_edges, np.int32))
+    meta = {"source": "moonrtx.moon_grid.create_moon_grid + merge_segments_to_graph (moon_grid.py:27-46, :689-790)",
+            "lines": {"pos_shape": list(np.shape(lines_pos)), "edges_shape": list(np.shape(lines_edges)),
+                      "pos_sum": float(np.sum(np.asarray(lines_pos, np.float64))), "pos_abs_sum": float(np.abs(lines_pos).sum()),
+                      "edge_sum": int(np.sum(lines_edges))},
+            "labels": {"pos_shape": list(np.shape(labels_pos)), "edges_shape": list(np.shape(labels_edges)),
+                       "pos_abs_sum": float(np.abs(labels_pos).sum()), "edge_sum": int(np.sum(labels_edges))},
+            "radii": {"grid_line": 0.006, "grid_label": 0.012}, "colour": [0.5, 0.5, 0.5]}
+    json.dump(meta, open(os.path.join(HERE, "moon_grid_graphs.json"), "w"), indent=1)
+    print("grid graphs:", meta["lines"]["pos_shape"], meta["lines"]["edges_shape"], meta["labels"]["pos_shape"], meta["labels"]["edges_shape"])
+
 if __name__ == "__main__":
     main()
+    grid_graphs()

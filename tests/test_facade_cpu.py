@@ -190,3 +190,41 @@ def test_unsupported_pieces_are_explicit():
     with pytest.raises(ValueError):
         rt.set_texture_2d("t", np.zeros((4, 4, 3), np.uint8))
     rt.close()
+
+
+def test_reference_grid_graphs_become_capsules():
+    """The graphs moon_grid.create_moon_grid() + merge_segments_to_graph() produce in the reference (golden:
+    tests/golden/moon_grid_graphs.npz, made by importing moonrtx.moon_grid) through set_graph / update_graph the way
+    renderer_labels.py:291-300, :209, :324-325 drive them."""
+    import json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(here, "moon_grid_graphs.npz"))
+    meta = json.load(open(os.path.join(here, "moon_grid_graphs.json")))
+    assert list(g["lines_pos"].shape) == meta["lines"]["pos_shape"] == [3300, 3]
+    assert list(g["lines_edges"].shape) == meta["lines"]["edges_shape"] == [3267, 2]
+    assert list(g["labels_pos"].shape) == meta["labels"]["pos_shape"] == [1266, 3]
+    assert list(g["labels_edges"].shape) == meta["labels"]["edges_shape"] == [633, 2]
+    assert int(g["lines_edges"].sum()) == meta["lines"]["edge_sum"] and int(g["labels_edges"].sum()) == meta["labels"]["edge_sum"]
+    assert np.abs(g["lines_pos"]).sum() == pytest.approx(meta["lines"]["pos_abs_sum"], rel=1e-6)
+    # grid lines sit on the sphere of radius 10 * 1.02 (moon_grid.py:689-694), outside the bounding sphere
+    assert np.allclose(np.linalg.norm(g["lines_pos"], axis=1), 10.2, atol=1e-4)
+    assert np.linalg.norm(g["labels_pos"], axis=1).min() > 10.0
+
+    rt, be, _ = make()
+    rt.set_graph("grid_lines", pos=g["lines_pos"], edges=g["lines_edges"], r=meta["radii"]["grid_line"], c=meta["colour"],
+                 mat="grid_material")
+    caps = be.last("set_capsules")[1][0]
+    assert caps.shape == (3267, 12)
+    assert np.array_equal(caps[:, 0:3], g["lines_pos"][g["lines_edges"][:, 0]])
+    assert np.array_equal(caps[:, 4:7], g["lines_pos"][g["lines_edges"][:, 1]])
+    assert np.allclose(caps[:, 3], 0.006) and np.allclose(caps[:, 8:11], 0.5)
+    rt.set_graph("grid_labels", pos=g["labels_pos"], edges=g["labels_edges"], r=meta["radii"]["grid_label"], c=meta["colour"],
+                 mat="grid_material")
+    assert be.last("set_capsules")[1][0].shape == (3267 + 633, 12)
+    R = sc.libration_rotation(4.0, -6.0)                                  # update_view: labels follow the libration
+    rt.update_graph("grid_labels", pos=g["labels_pos"] @ R.T)
+    caps = be.last("set_capsules")[1][0]
+    assert caps.shape == (3900, 12) and np.allclose(np.linalg.norm(caps[3267:, 0:3], axis=1), np.linalg.norm(g["labels_pos"][g["labels_edges"][:, 0]], axis=1), atol=1e-4)
+    rt.update_graph("grid_lines", r=0.0); rt.update_graph("grid_labels", r=0.0)      # show_moon_grid(False)
+    assert len(be.last("set_capsules")[1][0]) == 0
+    rt.close()

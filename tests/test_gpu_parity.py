@@ -234,6 +234,31 @@ def test_overlay_tubes_match_oracle(native_lib, dem_small):
             rt.close()
 
 
+def test_reference_moon_grid_overlay_matches_oracle(native_lib, dem_small):
+    """The reference's own overlay graphs (golden from moonrtx.moon_grid: 3267 grid-line edges at r = 0.006 + 633 label
+    edges at r = 0.012, colour 0.5; renderer_labels.py:24-28, :291-300) rotated by the libration, over the terrain."""
+    import os
+    from moonrtx_amd import overlays
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "moon_grid_graphs.npz"))
+    s = named_scene("S1", 240, 160, spp_per_launch=8)
+    R = np.asarray(s.rotation, float)
+    caps = np.concatenate([overlays.graph_to_capsules(g["lines_pos"] @ R.T, g["lines_edges"], 0.006, [0.5, 0.5, 0.5]),
+                           overlays.graph_to_capsules(g["labels_pos"] @ R.T, g["labels_edges"], 0.012, [0.5, 0.5, 0.5])])
+    assert caps.shape == (3900, 12)
+    for scene, tile in ((s, (32, 32)), (named_scene("S2", 160, 120, spp_per_launch=16, libration=(40.0, 25.0)), (16, 16))):
+        if scene is not s:
+            scene.vfov_deg = 1.1; scene.target = (1.0, 0.0, 2.0)          # zoom on a grid crossing with labels
+            Rz = np.asarray(scene.rotation, float)
+            caps = np.concatenate([overlays.graph_to_capsules(g["lines_pos"] @ Rz.T, g["lines_edges"], 0.006, [0.5, 0.5, 0.5]),
+                                   overlays.graph_to_capsules(g["labels_pos"] @ Rz.T, g["labels_edges"], 0.012, [0.5, 0.5, 0.5])])
+        lin_h, hits_h, st_h, _ = render_hip(scene, dem_small, capsules=caps, tile=tile)
+        lin_o, hits_o, st_o = render_oracle(scene, dem_small, capsules=caps)
+        assert_bit_equal(lin_h, lin_o, "grid overlay radiance"); assert_bit_equal(hits_h, hits_o, "grid overlay hits")
+        assert {k: st_h[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
+        base, _, _, _ = render_hip(scene, dem_small, tile=tile)
+        assert ((lin_h != base).any(-1)).sum() > 300                          # the grid is visible
+
+
 def test_other_radius_centre_step_and_deep_relief(native_lib, dem_small):
     """Nothing may be tied to R = 10 at the origin, step 5e-3 or ~1 % relief (skip bounds, mip cell, guards)."""
     from moonrtx_amd import overlays
