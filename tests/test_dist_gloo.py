@@ -31,10 +31,11 @@ class OracleShardRenderer:
         x0, y0 = tx * TILE[0], ty * TILE[1]
         return x0, y0, min(self.W, x0 + TILE[0]), min(self.H, y0 + TILE[1])
 
-    def render(self):
+    def render(self, n_blocks=1):
         for t in self.mine:
             self.o.blocks_done = 0
-            self.o.render(1, self._box(t))
+            self.o.render(n_blocks, self._box(t))
+        return {"kernel_ms": 0.0}
 
     def shard_bytes(self):
         return self.slots * TILE[0] * TILE[1] * 32
@@ -77,9 +78,8 @@ def _worker(rank, world, port, out_path):
     dem = synth_np.dem(90, 180, seed=5, craters=10)
     scene = named_scene("S1", 70, 52, spp_per_launch=4)          # ragged: not a multiple of the tile
     rend = OracleShardRenderer(scene, dem, rank, world)
-    rend.render()
     g = mdist.FrameGather(rend, torch.device("cpu"))
-    g.gather()
+    g.render_and_gather(1)            # what bench.py's step() calls (no part support here: render + one gather)
     if rank == 0:
         np.savez(out_path, accum=rend.o.accum, hits=rend.o.hits)
     torch.distributed.barrier()
