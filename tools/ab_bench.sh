@@ -4,6 +4,6 @@ cd $GRAFT_REPO_ROOT
 for round in 1 2; do
 for lib in "$@"; do
   if [ "$lib" = "default" ]; then unset MOONRT_LIB; else export MOONRT_LIB=$GRAFT_REPO_ROOT/$lib; fi
-  python bench.py --steps 5 --warmup 1 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | grep '^{' | python -c "
+  python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary $BENCH_ARGS 2>/dev/null | grep '^{' | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$lib', 'round $round', d['value'], 'Mrays/s', d['kernel_ms'], 'ms frac', d['roofline']['frac'])"
 done; done
