@@ -410,10 +410,12 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
             step_loop<WIDE, PRIMARY, STATS, false, BATCH>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
         PROF_END(7);
 #ifdef MRTX_PROF
+#ifndef MRTX_PROF_SPREAD
         cnt[8] += 1;                                     // wave-level segments
         cnt[9] += (uint32_t)__popcll(__ballot(true));    // lanes alive in them
         cnt[PRIMARY ? 13 : 14] += (__ballot(sg.jlo <= sg.jhi) == 0ull) ? 1u : 0u;   // wave-level segments nobody steps in
         cnt[15] += PRIMARY ? 1u : 0u;
+#endif
 #endif
         if (go) {
             // still marching after the last evaluated step: did the ray end inside the skipped tail?
@@ -703,6 +705,25 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         hit = march<WIDE, true, STATS, BATCH>(f, pa, pb, pc, da, db, dc, smax, sg, hi, cnt);
         PROF_END(2);
         PROF_BEGIN(3);
+#ifdef MRTX_PROF_SPREAD   // measurement only: spread of the lanes' texel coordinates at the primary hit (would an LDS tile cover the wave?)
+        {
+            const float u = (hi - sg.sa) * f.inv_step;
+            float rw = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra), cl = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
+            float rmin = hit ? rw : 1e30f, rmax = hit ? rw : -1e30f, cmin = hit ? cl : 1e30f, cmax = hit ? cl : -1e30f;
+            for (int m = 1; m < 64; m <<= 1) {
+                rmin = fminf(rmin, __shfl_xor(rmin, m, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, m, 64));
+                cmin = fminf(cmin, __shfl_xor(cmin, m, 64)); cmax = fmaxf(cmax, __shfl_xor(cmax, m, 64));
+            }
+            const float er = rmax - rmin, ec = cmax - cmin;
+            if (__ballot(hit) != 0ull) {
+                const float e = fmaxf(er, ec);
+                cnt[13] += (e <= 8.0f) ? 1u : 0u;
+                cnt[14] += (e <= 16.0f) ? 1u : 0u;
+                cnt[15] += (e <= 28.0f) ? 1u : 0u;
+                cnt[9] += 1u;
+            }
+        }
+#endif
         if (hit) {
             // hi = (float)k * step of the first sample below; k recovered exactly (|k*step/step - k| << 0.5)
             const int k = (int)rintf(hi * f.inv_step);
