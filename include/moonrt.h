@@ -102,13 +102,15 @@ int mrtx_abi_version(void);
  * equirectangular, row 0 = +90 deg, column 0 = -180 deg, max exactly 1.0. */
 int mrtx_upload_dem(mrtx_ctx* ctx, const float* host, int32_t h, int32_t w);
 /* Same, from a device pointer (synthetic / device-built DEMs).  Either way the context keeps its OWN copy,
- * re-laid-out with a one-texel border (wrap in longitude, clamp in latitude) so a bilinear evaluation on
- * the march path is two unconditional 8-byte loads; the caller may free its buffer when the call returns. */
+ * re-laid-out in row pairs -- element (r, c) = float2 (D[r][c], D[r+1][c]) -- with a two-texel border (wrap in longitude,
+ * clamp in latitude), so a bilinear evaluation on the march path is ONE unconditional 16-byte load; 8 bytes per texel.
+ * The caller may free its buffer when the call returns. */
 int mrtx_bind_dem_device(mrtx_ctx* ctx, const void* dev_f32, int32_t h, int32_t w);
 
 /* rt.set_texture_2d("moon_color", rgba_u8) + update_material("diffuse", {"ColorTextures": [...]})
  * -- moon_renderer.py:613-617.  NULL => const_albedo of MrtxParams. */
 int mrtx_upload_color(mrtx_ctx* ctx, const uint8_t* rgba, int32_t h, int32_t w);
+/* Same, from a device pointer; the context keeps its own row-pair copy (8 bytes per texel), the caller's array is read once. */
 int mrtx_bind_color_device(mrtx_ctx* ctx, const void* dev_rgba8, int32_t h, int32_t w);
 
 /* rt.set_background_mode("TextureEnvironment"); rt.set_background(star_map, gamma=, rt_format="UByte4")

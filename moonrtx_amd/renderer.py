@@ -103,7 +103,7 @@ class MoonRT:
         self._keepalive.pop("dem", None)
 
     def bind_dem(self, buf, h, w):
-        """Ingest a device-resident float32 (h, w) DEM; the context makes its own padded copy."""
+        """Ingest a device-resident float32 (h, w) DEM; the context makes its own row-pair copy (8 B per texel)."""
         self._check(self._lib.mrtx_bind_dem_device(self._ctx, buf.ptr, h, w), "mrtx_bind_dem_device")
 
     def upload_color(self, rgba):
@@ -118,7 +118,6 @@ class MoonRT:
 
     def bind_color(self, buf, h, w):
         self._check(self._lib.mrtx_bind_color_device(self._ctx, buf.ptr if buf else None, h, w), "mrtx_bind_color_device")
-        self._keepalive["color"] = buf
 
     def upload_background(self, rgba):
         if rgba is None:
