@@ -295,6 +295,9 @@ __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float 
 #ifndef MRTX_STEP_BATCH
 #define MRTX_STEP_BATCH 2
 #endif
+#ifndef MRTX_STEP_BATCH_BOUNCE
+#define MRTX_STEP_BATCH_BOUNCE 1
+#endif
 template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE, int BATCH>
 __device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                           float smax, const Seg& sg, int ka, bool& go, bool& hit, float& sk_out,
@@ -638,7 +641,7 @@ struct SampleOut {
 template <bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
-    constexpr int BATCH = BOUNCE ? 1 : MRTX_STEP_BATCH;   // incoherent bounce rays waste the speculative fetches
+    constexpr int BATCH = BOUNCE ? MRTX_STEP_BATCH_BOUNCE : MRTX_STEP_BATCH;   // incoherent bounce rays waste the speculative fetches
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
     const uint32_t kp = mix32(pix + CF(f)->key0);
     const uint32_t ks = mix32(kp ^ (gs * 0x85EBCA6Bu + 1u));
@@ -865,7 +868,7 @@ __device__ __forceinline__ float tree_sum(float v) {
 #define MRTX_WG_WAVES 1
 #endif
 #ifndef MRTX_MIN_WAVES
-#define MRTX_MIN_WAVES 5   // 93 VGPRs, 5 waves/SIMD, no spill: 4 measures the same, 6 and 8 slower (spills)
+#define MRTX_MIN_WAVES 4   // 4 waves/SIMD (128-VGPR budget): 13.57 ms at cfg3 against 13.87 with 5 (96), 14.8 with 6; 3 = 4
 #endif
 #ifndef MRTX_XCD_SHARE
 #define MRTX_XCD_SHARE 1   // 0 = always whole tiles per XCD (A/B switch, see the remap in render_kernel)
