@@ -237,7 +237,9 @@ def main():
                          "traffic": None if traffic is None else round(traffic["hbm_bytes_per_launch"]),
                          "traffic_source": None if traffic is None else f"profiles/{traffic['tag']}_summary.md: FETCH_SIZE x {traffic['fetch_factor']} (calibrated on a known 8-byte-per-lane stream) + WRITE_SIZE",
                          "algorithmic_bytes": int(algorithmic_bytes(counted, W, H) + px_adj),
-                         "kernel": "mrtx::render_kernel<64,false,false>",
+                         "kernel": "mrtx::render_kernel<%d, false, %s, %s, false>" % (
+                             S, "true" if (dem_h + 4) * (dem_w + 4) * 8 > 0xFFFFFFFF else "false",
+                             "true" if args.path_seg[1] > 1 else "false"),
                          "achieved_nominal": round(ach_nom, 1), "frac_nominal": round(ach_nom / HBM_PEAK_GBS, 4),
                          "note": "achieved = algorithmic bytes / HIP-event launch duration, bytes = 16 B per DEM "
                                  "evaluation PERFORMED + 4 B per max-mip texel + 16 B per colour fetch + 4 B per "
