@@ -817,16 +817,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         if (STATS) cnt[ST_BOUNCE]++;
         Seg bsg;
         float bhi = 0.0f;
-#if defined(MRTX_EXP_BOUNCE) && MRTX_EXP_BOUNCE == 2      // timing experiment: no bounce march at all
-        bool bhit = false;
-#else
-        bool bhit = march<WIDE, false, STATS, BATCH>(f, boa, bob, boc, bda, bdb, bdc, 0.0f, bsg, bhi, cnt);
-#endif
-#if defined(MRTX_EXP_BOUNCE) && MRTX_EXP_BOUNCE == 1      // timing experiment: march, then pretend it escaped
-        asm volatile("" :: "v"((int)bhit), "v"(bhi));
-        bhit = false;
-#endif
-        if (!bhit) {
+        if (!march<WIDE, false, STATS, BATCH>(f, boa, bob, boc, bda, bdb, bdc, 0.0f, bsg, bhi, cnt)) {
             if (CF(f)->bg) {   // the path leaves the Moon: environment radiance along its direction (scene frame)
                 const float ex = fmaf(bdc, CF(f)->Mf[2][0], fmaf(bdb, CF(f)->Mf[1][0], bda * CF(f)->Mf[0][0]));
                 const float ey = fmaf(bdc, CF(f)->Mf[2][1], fmaf(bdb, CF(f)->Mf[1][1], bda * CF(f)->Mf[0][1]));
