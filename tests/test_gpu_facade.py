@@ -55,3 +55,37 @@ def test_facade_render_thread_on_gpu(native_lib):
     assert done.wait(30.0)
     assert rt.get_image()[..., :3].max() > 0
     rt.close()
+
+
+def test_rendered_phase_matches_the_ephemeris(native_lib):
+    """Date + observer -> ephemeris -> scene -> HIP render of a smooth sphere: the lit fraction of the disc equals the
+    illuminated fraction k = (1 + cos i) / 2, and the lit side points along the bright-limb angle (measured from 'up'
+    towards celestial east, which is to the LEFT in the view)."""
+    import math
+    from datetime import datetime, timedelta, timezone
+    from moonrtx_amd import ephemeris as E
+    from moonrtx_amd.renderer import MoonRT
+    E.init(E.Observer(52.2, 21.0, 100))
+    dem = np.ones((16, 32), np.float32)
+    W = H = 256
+    for days in (3.0, 7.4, 11.0, 18.5, 24.0):
+        dt = datetime(2025, 3, 29, 11, 0, tzinfo=timezone.utc) + timedelta(days=days)      # new moon 2025-03-29 10:58 UTC
+        for mode in (True, False):
+            e = E.calculate_moon_ephemeris(dt, mode)
+            s = E.scene_from_ephemeris(e, W, H, spp_per_launch=16)
+            rt = MoonRT(W, H)
+            rt.upload_dem(dem); rt.apply_scene(s); rt.render(1)
+            lin = rt.read_linear(); rt.close()
+            disc = lin[..., 3] > 0.5
+            lit = disc & (lin[..., 0] > 0.0)                  # the Sun's 0.27 deg radius softens the terminator by ~0.2 % of the disc
+            k = (1.0 + math.cos(math.radians(e.phase_angle))) / 2.0
+            assert abs(lit.sum() / disc.sum() - k) < 0.02, (days, mode, lit.sum() / disc.sum(), k)
+            ys, xs = np.nonzero(lit)
+            cx, cy = xs.mean() - (W - 1) / 2.0, (H - 1) / 2.0 - ys.mean()                 # image x right, y up
+            got = math.degrees(math.atan2(-cx, cy))                                      # from up towards the left
+            if 0.05 < k < 0.95:
+                assert abs(E.wrap_signed_degrees(got - e.bright_limb_angle)) < 3.0, (days, mode, got, e.bright_limb_angle)
+            # the disc fills 0.9 of the frame height at the reference distance and scales with the apparent radius
+            # (moon_renderer.py:522-544: the camera distance follows the topocentric distance)
+            scale = math.asin(1737.4 / e.distance) / math.asin(1737.4 / 384400.0)
+            assert abs(disc.sum() / (math.pi * (0.45 * H * scale) ** 2) - 1.0) < 0.02, (days, disc.sum(), scale)
