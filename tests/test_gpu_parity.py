@@ -480,3 +480,80 @@ def test_errors_are_reported_not_fatal(native_lib):
     rt.close()
     with pytest.raises(MoonRTError):
         MoonRT(0, 10)
+
+
+def test_render_and_gather_async_branch_with_a_stand_in_collective(native_lib, dem_small, monkeypatch):
+    """FrameGather.render_and_gather()'s overlapped branch -- parts, slice offsets, async works, unpack -- with `world`
+    ranks as threads on one GPU and a stand-in for torch.distributed.gather that does what the collective does
+    (rendezvous of all ranks per call, copy of every rank's slice into the root's list).  The real RCCL call pattern
+    is covered by test_rccl_async_gather_of_views; a multi-rank RCCL run needs the 8-GPU node."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(r"""
+        import sys, threading
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, "tests")
+        import synth_np
+        from moonrtx_amd import dist as mdist
+        from moonrtx_amd.renderer import MoonRT
+        from moonrtx_amd.scene import named_scene
+
+        world = int(sys.argv[1])
+        lock = threading.Lock()
+        calls = {}                                   # call index -> {"bar": Barrier, "src": {rank: tensor}, "dst": list}
+        counters = [0] * world
+        tls = threading.local()
+
+        class Work:
+            def __init__(self, slot, rank): self.slot, self.rank = slot, rank
+            def wait(self):
+                self.slot["bar"].wait()              # every rank has deposited
+                if self.rank == 0:
+                    for r, t in self.slot["src"].items():
+                        self.slot["dst"][r].copy_(t)
+                    torch.cuda.synchronize()
+                self.slot["bar2"].wait()
+
+        def fake_gather(tensor, gather_list=None, dst=0, async_op=False):
+            rank = tls.rank
+            k = counters[rank]; counters[rank] += 1
+            with lock:
+                slot = calls.setdefault(k, {"bar": threading.Barrier(world), "bar2": threading.Barrier(world), "src": {}, "dst": None})
+                slot["src"][rank] = tensor
+                if rank == 0: slot["dst"] = gather_list
+            w = Work(slot, rank)
+            if async_op: return w
+            w.wait()
+
+        dist.gather = fake_gather
+        dist.get_backend = lambda *a, **k: "nccl"
+        dem = synth_np.dem(90, 180, seed=5, craters=10)
+        scene = named_scene("S1", 192, 96, spp_per_launch=8)
+        ref = MoonRT(scene.width, scene.height, tile=(16, 16)); ref.upload_dem(dem); ref.apply_scene(scene); ref.render(1)
+        want, want_h = ref.read_linear(), ref.read_hits(); ref.close()
+        out, errs = {}, []
+        def run(rank):
+            try:
+                tls.rank = rank
+                rt = MoonRT(scene.width, scene.height, rank=rank, world=world, tile=(16, 16))
+                rt.upload_dem(dem); rt.apply_scene(scene)
+                g = mdist.FrameGather(rt, torch.device("cuda", 0))
+                assert rt.shard_parts(2) == 2
+                for _ in range(2):                   # twice: buffers and counters are reused
+                    rt.reset()
+                    st = g.render_and_gather(1, parts=2)
+                assert g.last_bytes == rt.shard_bytes_active() < rt.shard_bytes()
+                if rank == 0: out["lin"], out["hits"] = rt.read_linear(), rt.read_hits()
+                rt.close()
+            except Exception as e:
+                errs.append((rank, repr(e)))
+                for s in list(calls.values()): s["bar"].abort(); s["bar2"].abort()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]; [t.join(120) for t in th]
+        assert not errs, errs
+        assert np.array_equal(out["lin"].view(np.uint32), want.view(np.uint32)), "radiance"
+        assert np.array_equal(out["hits"].view(np.uint32), want_h.view(np.uint32)), "hits"
+        print("ok", world, len(calls))
+    """)
+    for world in (2, 3):
+        r = subprocess.run([sys.executable, "-c", code, str(world)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
