@@ -18,11 +18,11 @@ for grp in "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_C
   rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- $BENCH > $OUT/g$i.log 2>&1 || echo "group $i ($grp) failed"
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, os
 acc = collections.defaultdict(list)
 for fn in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        if "render_kernel<64, false" in r["Kernel_Name"]:
+        if "render_kernel<64, false" in r["Kernel_Name"] and (os.environ.get("KMATCH", "") in r["Kernel_Name"]):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     print(f"{k:45s} {sum(acc[k])/len(acc[k]):16.4e}  n={len(acc[k])}")
