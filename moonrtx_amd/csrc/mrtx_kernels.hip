@@ -870,8 +870,13 @@ __device__ __forceinline__ float tree_sum(float v) {
 #ifndef MRTX_MIN_WAVES_BOUNCE
 #define MRTX_MIN_WAVES_BOUNCE 5   // 8 spilled VGPRs at 5 waves/SIMD still beat 4 waves without spills (36.1 vs 39.8 ms)
 #endif
+// The COUNTING bounce variants carry the counter array on top of the path state and want ~180 VGPRs: under the 96-VGPR
+// cap they spill ~200 registers, and in an experiment at a 72-VGPR cap one such instantiation (<64, STATS, !WIDE, BOUNCE,
+// OVERLAY>) miscomputed a sample with no undefined behaviour the compiler could name.  They only render the counted
+// frame, so they get the registers they ask for.
+#define MRTX_BOUNCE_WAVES(STATS) ((STATS) ? 2 : MRTX_MIN_WAVES_BOUNCE)
 template <int S, bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
-__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, BOUNCE ? MRTX_MIN_WAVES_BOUNCE : MRTX_MIN_WAVES)
+__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, BOUNCE ? MRTX_BOUNCE_WAVES(STATS) : MRTX_MIN_WAVES)
 render_kernel(const FrameC f) {
     constexpr int P = 64 / S;
     constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;

@@ -116,7 +116,8 @@ def cases(seed):
                 caps[i, 3] = s.radius * rng2.uniform(0.001, 0.03)
                 caps[i, 8:11] = rng2.random(3)
             capsules = caps
-        extra = dict(capsules=capsules, world=int(rng2.choice([1, 1, 2, 3])), parts=int(rng2.choice([1, 2, 3])))
+        extra = dict(capsules=capsules, world=int(rng2.choice([1, 1, 2, 3])), parts=int(rng2.choice([1, 2, 3])),
+                     count=bool(rng2.random() < 0.5))   # half of the cases run the production kernels (no counters)
         if rng2.random() < 0.12:                    # camera INSIDE the bounding sphere: low orbit, or under the terrain
             e = rng2.normal(size=3); e /= np.linalg.norm(e)
             s.eye = tuple(np.asarray(s.center, float) + e * s.radius * rng2.uniform(0.85, 0.9999))
@@ -164,6 +165,13 @@ def check_case(c):
     """Render one case on both sides and compare bit for bit; returns the oracle's statistics."""
     from common import STAT_KEYS, assert_bit_equal, render_hip, render_oracle
     desc, dem, col, bg, s, flags, tile, blocks, extra = c
+    import os
+    if os.environ.get("FUZZ_WORLD"):            # debugging aids: force the number of ranks / the flags
+        extra = dict(extra, world=int(os.environ["FUZZ_WORLD"]))
+    if os.environ.get("FUZZ_FLAGS"):
+        flags = int(os.environ["FUZZ_FLAGS"])
+    elif not extra.get("count", True):
+        flags &= ~_lib.F_COUNT_STATS
     caps = extra["capsules"]
     lin_o, hits_o, st_o = render_oracle(s, dem, col, bg, blocks=blocks, capsules=caps)
     if extra["world"] > 1:
@@ -174,7 +182,7 @@ def check_case(c):
     lin_h, hits_h, st_h, _ = render_hip(s, dem, col, bg, blocks=blocks, tile=tile, flags=flags, capsules=caps)
     assert_bit_equal(lin_h, lin_o, desc + ": radiance")
     assert_bit_equal(hits_h, hits_o, desc + ": hits")
-    if len(blocks) == 1:
+    if len(blocks) == 1 and (flags & _lib.F_COUNT_STATS):
         got = {k: st_h[k] for k in STAT_KEYS}
         want = {k: st_o[k] for k in STAT_KEYS}
         assert got == want, f"{desc}: counters {got} vs {want}"
