@@ -106,3 +106,22 @@ def test_crop_of_the_full_frame_matches_the_oracle(inputs):
         assert_bit_equal(got, want, f"crop at {x0},{y0}")
         assert_bit_equal(hits[y0:y0 + 64, x0:x0 + 96], o.hits[y0:y0 + 64, x0:x0 + 96], "crop hits")
     assert orc.quad_out_of_range() == 0
+
+
+def test_production_kernels_equal_the_counting_kernels_at_full_size(inputs):
+    """The kernels bench.py times carry no counters (flags = 0): separate template instantiations with their own
+    register allocation.  At full size they must reproduce the counting kernels' frame -- which the crop test above pins
+    to the oracle -- bit for bit, for the headline path and for the reference's path_seg_range (2, 4)."""
+    for spp, seg in ((64, (1, 1)), (16, (1, 1)), (64, (2, 4))):
+        frames = []
+        for flags in (_lib.F_COUNT_STATS, 0):
+            rt = make(inputs, spp)
+            s = named_scene("S1", W, H, spp_per_launch=spp)
+            s.path_seg_min, s.path_seg_max = seg
+            rt.apply_scene(s)
+            rt.set_params(flags=flags)
+            rt.render(1)
+            frames.append((rt.read_linear(), rt.read_hits()))
+            rt.close()
+        assert_bit_equal(frames[1][0], frames[0][0], f"production vs counting radiance, {spp} spp, path_seg {seg}")
+        assert_bit_equal(frames[1][1], frames[0][1], f"production vs counting hits, {spp} spp, path_seg {seg}")
