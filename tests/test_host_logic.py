@@ -63,3 +63,15 @@ def test_moon_axes_and_libration():
     assert np.allclose(u, R @ (0, 0, 1)) and np.allclose(v, R @ (0, -1, 0))
     u0, v0 = sc.moon_axes(np.eye(3))
     assert tuple(u0) == (0, 0, 1) and tuple(v0) == (0, -1, 0)      # moon_renderer.py:621
+
+
+def test_helper_scripts_parse():
+    """tools/ is not exercised by the suites: at least keep every script syntactically valid."""
+    import glob, os, py_compile, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(scripts) > 10
+    for path in scripts:
+        py_compile.compile(path, doraise=True)
+    for path in sorted(glob.glob(os.path.join(root, "tools", "*.sh"))):
+        assert subprocess.run(["bash", "-n", path]).returncode == 0, path
