@@ -56,6 +56,8 @@ struct mrtx_ctx {
     uint32_t* overlay = nullptr;   // D12: frame-sized RGBA8 blended over the tone-mapped image, or null
     unsigned long long* stats_dev = nullptr;
     FrameCold* cold_dev = nullptr;
+    FrameCold cold_uploaded;             // what cold_dev holds (valid once cold_valid): re-uploaded only when it changes
+    bool cold_valid = false;
     // D11 overlay capsules: host copy in scene coordinates; device copies relative to the Moon centre + tile bins
     std::vector<float> caps_host;            // 12 floats per capsule
     float* caps_dev = nullptr; int32_t* caps_off_dev = nullptr; int32_t* caps_idx_dev = nullptr;
@@ -678,11 +680,16 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     }
     FrameC f;
     FrameCold cold;
+    std::memset(&cold, 0, sizeof cold);      // padding included: the block is compared bytewise below
     build_frame(c, f, cold);
     f.cold = c->cold_dev;
     cold.caps = c->caps_dev; cold.caps_off = c->caps_off_dev; cold.caps_idx = c->caps_idx_dev;
     cold.n_caps = (int32_t)(c->caps_host.size() / 12);
-    HIPCHK(c, hipMemcpyAsync(c->cold_dev, &cold, sizeof cold, hipMemcpyHostToDevice, c->stream));
+    if (!c->cold_valid || std::memcmp(&cold, &c->cold_uploaded, sizeof cold) != 0) {
+        std::memcpy(&c->cold_uploaded, &cold, sizeof cold);
+        HIPCHK(c, hipMemcpyAsync(c->cold_dev, &c->cold_uploaded, sizeof cold, hipMemcpyHostToDevice, c->stream));
+        c->cold_valid = true;
+    }
     f.first_block = c->blocks_done;
     f.n_blocks = (uint32_t)n_blocks;
     const bool stats = (c->prm.flags & MRTX_F_COUNT_STATS) != 0;
