@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--dem-scale", type=int, default=1, help="debug: shrink the DEM by this factor")
     ap.add_argument("--path-seg", type=int, nargs=2, default=(1, 1), metavar=("MIN", "MAX"),
                     help="path length in segments; (1,1) = direct light only (headline), the reference sets (2,4)")
+    ap.add_argument("--inwave-paths", action="store_true", help="A/B: keep D6 paths inside the render wave (MRTX_F_INWAVE_PATHS)")
     args = ap.parse_args()
 
     import torch
@@ -157,20 +158,22 @@ def main():
         torch.cuda.synchronize()
 
     # one counted frame (deterministic sample counts for the roofline), untimed
-    rt.set_params(flags=_lib.F_COUNT_STATS)
+    base_flags = _lib.F_INWAVE_PATHS if args.inwave_paths else 0
+    rt.set_params(flags=_lib.F_COUNT_STATS | base_flags)
     counted = step()
-    rt.set_params(flags=0)
+    rt.set_params(flags=base_flags)
     for _ in range(args.warmup):
         step()
 
     barrier()
     t = time.perf_counter()
-    kernel_ms = 0.0
+    kernel_ms = primary_ms = paths_ms = 0.0
     for _ in range(args.steps):
-        kernel_ms += step()["kernel_ms"]
+        st_ = step()
+        kernel_ms += st_["kernel_ms"]; primary_ms += st_["primary_ms"]; paths_ms += st_["paths_ms"]
     barrier()
     elapsed = time.perf_counter() - t
-    kernel_ms /= max(1, args.steps)
+    kernel_ms /= max(1, args.steps); primary_ms /= max(1, args.steps); paths_ms /= max(1, args.steps)
 
     # whole-job numbers: max time over ranks, counts summed over ranks
     red_dev = "cpu" if backend == "gloo" else "cuda"
@@ -190,7 +193,7 @@ def main():
     if world == 1 and tuple(args.path_seg) == (1, 1) and not args.no_secondary:
         scene.path_seg_min, scene.path_seg_max = 2, 4
         rt.apply_scene(scene)
-        rt.set_params(flags=0)
+        rt.set_params(flags=base_flags)
         step()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -228,7 +231,7 @@ def main():
                                       + (", RCCL gather of float4 radiance+hits to rank 0" if world > 1 else ""),
                        "march": "step 5e-3, eps 3e-4, scene_epsilon 1e-4, 1 light sample + shadow ray per path vertex, "
                                 f"path_seg_range {tuple(args.path_seg)}" + (" (direct light only)" if args.path_seg[1] <= 1 else "")},
-            "kernel_ms": round(kernel_ms, 3),
+            "kernel_ms": round(kernel_ms, 3), "primary_ms": round(primary_ms, 3), "paths_ms": round(paths_ms, 3),
             "frame_counts": frame,
             "bytes_per_ray": round(algorithmic_bytes(frame, W, H) / rays, 2),
             "bytes_per_ray_nominal": round(algorithmic_bytes(frame, W, H, nominal=True) / rays, 2),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRTX_ABI_VERSION 5
+#define MRTX_ABI_VERSION 6
 
 enum {
     MRTX_OK = 0,
@@ -72,6 +72,8 @@ typedef struct MrtxParams {
 #define MRTX_F_NO_CULL     8u  /* dispatch every tile (disable the host-side sky-tile cull) */
 #define MRTX_F_NO_SORT     16u /* dispatch tiles in raster order (disable the limb-ring-first launch order) */
 #define MRTX_F_FORCE_WIDE  2u  /* test hook: use the 64-bit DEM addressing path (normally only for DEMs > 4 GiB) */
+#define MRTX_F_INWAVE_PATHS 32u /* path_seg_max > 1: keep the whole path inside the wave that traced the camera ray instead
+                                   of continuing it behind a queue in path_kernel (same result bit for bit; A/B switch) */
 
 typedef struct MrtxStats {
     uint64_t primary_rays;        /* camera samples (pixel x spp), the headline "ray"      */
@@ -85,7 +87,11 @@ typedef struct MrtxStats {
                                      be above the terrain are skipped; results are unchanged)                  */
     uint64_t mip_fetches;         /* max-mip texels read for those bounds (4 B each)                           */
     uint64_t bounce_rays;         /* D6 path-continuation rays marched (0 when path_seg_max <= 1)              */
-    double kernel_ms;             /* HIP-event time of the render kernel(s) of this call   */
+    uint64_t bounce_sun_hits;     /* ... of which left the Moon and ended on the visible Sun disk              */
+    double kernel_ms;             /* HIP-event time of the kernels of this call = primary_ms + paths_ms        */
+    double primary_ms;            /* render_kernel: camera ray, first vertex, its direct light                 */
+    double paths_ms;              /* path_kernel + resolve_paths_kernel: everything after the first vertex
+                                     (0 unless path_seg_max > 1 and the queue-based path stage is in use)      */
     uint32_t launches;
     uint32_t reserved;
 } MrtxStats;

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOONRT_LIB") or os.path.join(_HERE, "libmoonrt.so")   # MOONRT_LIB: A/B builds only
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MrtxConfig(C.Structure):
@@ -29,7 +29,8 @@ class MrtxStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("primary_hits", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("height_samples", C.c_uint64), ("colour_fetches", C.c_uint64),
                 ("background_fetches", C.c_uint64), ("dem_fetches", C.c_uint64), ("mip_fetches", C.c_uint64), ("bounce_rays", C.c_uint64),
-                ("kernel_ms", C.c_double),
+                ("bounce_sun_hits", C.c_uint64),
+                ("kernel_ms", C.c_double), ("primary_ms", C.c_double), ("paths_ms", C.c_double),
                 ("launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
@@ -38,6 +39,7 @@ F_FORCE_WIDE = 2
 F_NO_SKIP = 4
 F_NO_CULL = 8
 F_NO_SORT = 16
+F_INWAVE_PATHS = 32
 BUF_ACCUM, BUF_HITS, BUF_DEM, BUF_COLOR = 0, 1, 2, 3
 
 _D3 = C.POINTER(C.c_double)

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -16,7 +17,10 @@
 #include "../../include/moonrt.h"
 #include "mrtx_device.h"
 
-hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, bool overlay, hipStream_t st);
+hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, int mode, bool overlay, const PathQ* pq, hipStream_t st);
+uint64_t mrtx_path_chunks(const FrameC& f, int S, uint32_t* grid_a, int* njobs_log2);
+int mrtx_path_waves(bool stats, bool wide, int* out);
+hipError_t mrtx_launch_paths(const FrameC& f, const PathQ& pq, int S, bool stats, int n_waves, hipStream_t st);
 hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t npix, uint32_t ns, hipStream_t st);
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
                                      float invg, const uint32_t* overlay, hipStream_t st);
@@ -46,6 +50,13 @@ struct mrtx_ctx {
     int tiles_x = 0, tiles_y = 0, n_tiles = 0, n_local = 0, slots = 0, tile_shift = 3;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> evs;         // stage boundaries of a deferred-path call (3 per block)
+    // hand-over records of the deferred path stage (PathQ): 6 float arrays of 64 x chunks + one word per chunk
+    float* path_rec = nullptr; uint32_t* path_meta = nullptr; uint64_t path_cap = 0;
+    uint32_t* path_ctr = nullptr;        // 8 x 16 work counters of path_kernel
+    int path_nsub = 4, path_grp_log2 = 1;
+    int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
+    int path_refill = 8, path_segmin = 24, path_hitmin = 16, path_policy = 0, path_waves_env = 0;
     float* accum = nullptr;
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
@@ -184,6 +195,12 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     for (int i = 0; i < 3; i++) { sr[i] = c->sun_pos[i] - c->eye[i]; k.sc[i] = (float)sr[i]; }
     k.sun_cq = (float)(((sr[0] * sr[0] + sr[1] * sr[1]) + sr[2] * sr[2]) - c->sun_radius * c->sun_radius);
     k.sun_rad = (float)c->sun_radiance;
+    {
+        double sm[3];
+        for (int i = 0; i < 3; i++) sm[i] = c->sun_pos[i] - c->center[i];
+        for (int i = 0; i < 3; i++) k.Sb[i] = (float)((k.M[i][0] * sm[0] + k.M[i][1] * sm[1]) + k.M[i][2] * sm[2]);
+        k.sun_r2 = (float)(c->sun_radius * c->sun_radius);
+    }
     f.step = c->prm.marching_step;
     k.eps = c->prm.marching_step_eps;
     k.scene_eps = c->prm.scene_epsilon;
@@ -414,6 +431,16 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
     if (c->cfg.tile_h <= 0) c->cfg.tile_h = 32;
     if ((c->cfg.tile_w & 15) || (c->cfg.tile_h & 15)) { delete c; return MRTX_E_INVALID; }
     mrtx_default_params(&c->prm);
+    {   // tuning knobs of the deferred path stage (measurement aid; the defaults are what bench.py times)
+        const char* e;
+        if ((e = std::getenv("MOONRT_PATH_REFILL")) && std::atoi(e) >= -64 && std::atoi(e) <= 64) c->path_refill = std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_SEGMIN")) && std::atoi(e) >= -64 && std::atoi(e) <= 64) c->path_segmin = std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_HITMIN")) && std::atoi(e) >= -64 && std::atoi(e) <= 64) c->path_hitmin = std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_NSUB")) && std::atoi(e) >= 1 && std::atoi(e) <= 16) c->path_nsub = std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_GRP")) && std::atoi(e) >= 0 && std::atoi(e) <= 10) c->path_grp_log2 = std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_POLICY"))) c->path_policy = std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_WAVES")) && std::atoi(e) >= 8) c->path_waves_env = std::atoi(e) / 8 * 8;
+    }
     c->tiles_x = (cfg->width + c->cfg.tile_w - 1) / c->cfg.tile_w;
     c->tiles_y = (cfg->height + c->cfg.tile_h - 1) / c->cfg.tile_h;
     c->n_tiles = c->tiles_x * c->tiles_y;
@@ -454,6 +481,10 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->tile_list_dev) (void)hipFree(c->tile_list_dev);
     if (c->act_dev) (void)hipFree(c->act_dev);
     if (c->stale_dev) (void)hipFree(c->stale_dev);
+    if (c->path_rec) (void)hipFree(c->path_rec);
+    if (c->path_meta) (void)hipFree(c->path_meta);
+    if (c->path_ctr) (void)hipFree(c->path_ctr);
+    for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
     if (c->color) (void)hipFree(c->color);
@@ -743,24 +774,93 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         c->tile_dirty.assign((size_t)c->n_local, 1);
     }
     if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 16 * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, mrtx_launch_render(f, (int)c->prm.spp_per_launch, stats, c->prm.path_seg_max > 1, overlay, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // D6 (path_seg_max > 1): by default the path continues in path_kernel behind a queue (mode 2);
+    // MRTX_F_INWAVE_PATHS keeps it inside the render wave (mode 1) -- same result bit for bit, slower.
+    const int S = (int)c->prm.spp_per_launch;
+    const int mode = c->prm.path_seg_max > 1 ? ((c->prm.flags & MRTX_F_INWAVE_PATHS) ? 1 : 2) : 0;
+    double primary_ms = 0.0, paths_ms = 0.0;
+    uint32_t launches = 0;
+    if (mode != 2) {
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        HIPCHK(c, mrtx_launch_render(f, S, stats, mode, overlay, nullptr, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        primary_ms = ms;
+        launches = 1;
+    } else {
+        PathQ pq;
+        std::memset(&pq, 0, sizeof pq);
+        const uint64_t chunks = mrtx_path_chunks(f, S, &pq.grid_a, &pq.njobs_log2);
+        if (chunks * 64ull > 0xFFFFFFFFull) return fail(c, MRTX_E_INVALID, "frame too large for one deferred-path launch (%llu chunks)", (unsigned long long)chunks);
+        if (chunks > c->path_cap) {
+            if (c->path_rec) { HIPCHK(c, hipFree(c->path_rec)); c->path_rec = nullptr; }
+            if (c->path_meta) { HIPCHK(c, hipFree(c->path_meta)); c->path_meta = nullptr; }
+            c->path_cap = 0;
+            if (hipMalloc((void**)&c->path_rec, (size_t)chunks * 64 * MRTX_PATH_REC_BYTES) != hipSuccess ||
+                hipMalloc((void**)&c->path_meta, (size_t)chunks * sizeof(uint32_t)) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, MRTX_E_NOMEM, "no device memory for %llu path records (%.1f GB); MRTX_F_INWAVE_PATHS needs none",
+                            (unsigned long long)(chunks * 64), (double)chunks * 64 * MRTX_PATH_REC_BYTES / 1e9);
+            }
+            c->path_cap = chunks;
+        }
+        const size_t n = (size_t)chunks * 64;
+        pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
+        pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n;
+        pq.meta = c->path_meta;
+        if (!c->path_ctr) HIPCHK(c, hipMalloc((void**)&c->path_ctr, 8 * 16 * sizeof(uint32_t)));
+        pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
+        pq.n_chunks = (uint32_t)chunks;
+        pq.s_log2 = 0;
+        while ((1 << pq.s_log2) < S) pq.s_log2++;
+        { const int P = 64 / S; const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1; pq.pw_log2 = PW == 8 ? 3 : PW == 4 ? 2 : PW == 2 ? 1 : 0; }
+        pq.refill_min = c->path_refill; pq.seg_min = c->path_segmin; pq.rare_min = c->path_hitmin; pq.policy = c->path_policy;
+        const int wi = (stats ? 2 : 0) + (f.dem_wide ? 1 : 0);
+        if (c->path_waves[wi] == 0) {
+            int nw = 0;
+            if (mrtx_path_waves(stats, f.dem_wide != 0, &nw) != 0 || nw < 8) return fail(c, MRTX_E_DEVICE, "cannot size the path_kernel launch");
+            c->path_waves[wi] = nw;
+        }
+        const int nw = c->path_waves_env ? c->path_waves_env : c->path_waves[wi];
+        while (c->evs.size() < (size_t)n_blocks * 3) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->evs.push_back(e); }
+        for (int32_t b = 0; b < n_blocks; b++) {
+            FrameC fb = f;
+            fb.first_block = c->blocks_done + (uint32_t)b;
+            fb.n_blocks = 1;
+            pq.gs_base = fb.first_block * (uint32_t)S;
+            HIPCHK(c, hipMemsetAsync(c->path_meta, 0, (size_t)chunks * sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->path_ctr, 0, 8 * 16 * sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipEventRecord(c->evs[(size_t)b * 3], c->stream));
+            HIPCHK(c, mrtx_launch_render(fb, S, stats, 2, overlay, &pq, c->stream));
+            HIPCHK(c, hipEventRecord(c->evs[(size_t)b * 3 + 1], c->stream));
+            HIPCHK(c, mrtx_launch_paths(fb, pq, S, stats, nw, c->stream));
+            HIPCHK(c, hipEventRecord(c->evs[(size_t)b * 3 + 2], c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int32_t b = 0; b < n_blocks; b++) {
+            float a = 0.0f, p = 0.0f;
+            HIPCHK(c, hipEventElapsedTime(&a, c->evs[(size_t)b * 3], c->evs[(size_t)b * 3 + 1]));
+            HIPCHK(c, hipEventElapsedTime(&p, c->evs[(size_t)b * 3 + 1], c->evs[(size_t)b * 3 + 2]));
+            primary_ms += a; paths_ms += p;
+        }
+        launches = 3u * (uint32_t)n_blocks;
+    }
     if (part == n_parts - 1) c->blocks_done += (uint32_t)n_blocks;
     if (out) {
         std::memset(out, 0, sizeof *out);
-        float ms = 0.0f;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        out->kernel_ms = ms;
-        out->launches = 1;
+        out->kernel_ms = primary_ms + paths_ms;
+        out->primary_ms = primary_ms;
+        out->paths_ms = paths_ms;
+        out->launches = launches;
         if (stats) {
             unsigned long long h[16];
             HIPCHK(c, hipMemcpy(h, c->stats_dev, sizeof h, hipMemcpyDeviceToHost));
             out->primary_rays = h[0] + (part == 0 ? culled_px : 0) * (uint64_t)c->prm.spp_per_launch * (uint64_t)n_blocks;
             out->primary_hits = h[1]; out->shadow_rays = h[2];
             out->height_samples = h[3]; out->colour_fetches = h[4]; out->background_fetches = h[5];
-            out->dem_fetches = h[6]; out->mip_fetches = h[7]; out->bounce_rays = h[8];
+            out->dem_fetches = h[6]; out->mip_fetches = h[7]; out->bounce_rays = h[8]; out->bounce_sun_hits = h[9];
         }
     }
     return MRTX_OK;

@@ -56,6 +56,7 @@ struct FrameCold {
     // D8 Sun disk (moon_renderer.py:647-650)
     int32_t sun_on;
     float sc[3], sun_cq, sun_rad;
+    float Sb[3], sun_r2;    // disk centre in the moon frame (relative to the Moon centre), radius^2: continuation rays see it
     float eps, scene_eps;
     float dlat_scale, dlon_scale;
     GridC gc;
@@ -97,5 +98,34 @@ struct FrameC {
     uint32_t first_block, n_blocks;
     float* accum;           // W*H float4: running sums r,g,b,coverage
     float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block
-    unsigned long long* stats;  // 9 counters, see MrtxStats
+    unsigned long long* stats;  // 10 counters, see MrtxStats
 };
+
+// Hand-over between render_kernel<MODE 2> (camera ray, first vertex, its direct light, the decision to go on) and
+// path_kernel (everything after), one RECORD per lane of every wave-job ("chunk") of the render launch:
+//   ray0/1/2  float4 each: continuation-ray origin (3; ray0.x = MRTX_NO_PATH: this sample has no path to continue),
+//             direction (3), path throughput (3), exact DEM texel coordinates of the origin (2), RNG key of the sample (1)
+//   c0/1/2    the sample's radiance so far (direct term / Sun disk / environment / overlay colour); path_kernel writes
+//             the final value back when the path adds light, resolve_paths_kernel sums the 64 lanes in the butterfly
+//             order of the spec
+//   meta      per chunk: bit 31 = the chunk was deferred, bits 0-14 / 15-29 = pixel (x0, y0) of the wave's pixel block
+// A wave writes 1 KB (ray*) / 256 B (c*) contiguous per array.
+struct PathQ {
+    float4* ray0; float4* ray1; float4* ray2;
+    float* c0; float* c1; float* c2;
+    uint32_t* meta;
+    uint32_t n_chunks;          // wave-jobs of the render launch (grid x jobs per wave)
+    uint32_t grid_a;            // blocks of the render launch; chunk = block * jobs + job
+    int32_t njobs_log2;         // jobs (pixel blocks) per render wave: 1 or 2
+    uint32_t* counters;         // path_kernel's work counters: 8 XCDs x n_sub, zero before the launch
+    int32_t n_sub, grp_log2;    // counters per XCD; render blocks per group handed out = 1 << grp_log2
+    uint32_t gs_base;           // global sample index of sample 0 of this block (first_block * S)
+    int32_t s_log2, pw_log2;    // S = 1 << s_log2 samples per pixel in a wave, pixel block PW x PH, PW = 1 << pw_log2
+    int32_t refill_min;         // path_kernel refills its idle lanes when at least this many are idle
+    int32_t seg_min;            // ... sets up march segments when at least this many lanes need one
+    int32_t policy;             // 0: thresholds below, 1: greedy (run only the block most lanes wait for; *_min are score biases)
+    int32_t rare_min;           // ... and runs the rare steps (a continuation ray hit terrain; a vertex got its direct
+                                //     term) when at least this many lanes wait for them
+};
+#define MRTX_PATH_REC_BYTES 60  // per record: 3 x float4 + 3 x float
+#define MRTX_NO_PATH 1.0e30f

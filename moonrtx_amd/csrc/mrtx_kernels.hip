@@ -21,6 +21,7 @@
 // with -ffp-contract=off, correctly rounded / and sqrt (hipcc default), own polynomial atan/sin/cos.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "mrtx_device.h"
 
@@ -45,7 +46,7 @@ __device__ unsigned long long g_prof[16];
 #define PROF_END(i)
 #endif
 
-enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_FETCH, ST_MIP, ST_BOUNCE, ST_N };
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_FETCH, ST_MIP, ST_BOUNCE, ST_SUNHIT, ST_N };
 
 // atan(q) ~= q * P(q^2) on [0,1], |err| <= 1.3e-7
 __device__ __forceinline__ float atan_poly(float q) {
@@ -377,20 +378,28 @@ __device__ __forceinline__ uint32_t count_in_steps(const FrameC& f, float oa, fl
     return n;
 }
 
-// Coarse march s_k = k*step, k = 1, 2, ...; returns true and s_k at the first sample at/below the surface.
-// PRIMARY: stop when s_k > smax (left the bounding sphere); shadow rays: stop when r^2 > R^2.
-// A lane drops out of the exec mask when it hits or leaves, and the wave leaves the loop when no lane is still
-// marching.  f.kmax is a multiple of SEG_N.
-template <bool WIDE, bool PRIMARY, bool STATS, int BATCH>
-__device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
-                                      float smax, Seg& sg, float& sk_hit, uint32_t* cnt) {
-    float rowA, colA, q2A;
-    exact_rowcol(f, oa, ob, oc, rowA, colA, q2A);
+// Per-ray march state between segments: the ray, the coefficients of r^2(s) and the exact texel coordinates at the
+// start of the next segment (step ka).
+struct MarchState {
+    float oa, ob, oc, da, db, dc;
     RayQ rq;
-    rq.q0 = fmaf(oc, oc, q2A);
-    rq.b = fmaf(oc, dc, fmaf(ob, db, oa * da));
-    rq.a = fmaf(dc, dc, fmaf(db, db, da * da));
-    bool hit = false, go = true;
+    float rowA, colA, q2A;
+    int ka;
+};
+
+// Start of a march: exact coordinates at the origin, r^2(s) coefficients; returns `go` (false: the march is over before
+// its first step).
+// ... with the exact texel coordinates of the origin already known (m.rowA, m.colA)
+template <bool PRIMARY>
+__device__ __forceinline__ bool march_begin_at(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                               MarchState& m) {
+    m.oa = oa; m.ob = ob; m.oc = oc; m.da = da; m.db = db; m.dc = dc;
+    m.q2A = fmaf(ob, ob, oa * oa);
+    m.rq.q0 = fmaf(oc, oc, m.q2A);
+    m.rq.b = fmaf(oc, dc, fmaf(ob, db, oa * da));
+    m.rq.a = fmaf(dc, dc, fmaf(db, db, da * da));
+    m.ka = 0;
+    bool go = true;
     if (!PRIMARY) {
         // The skip below relies on "once outside, always outside".  r^2(s) is convex, so that holds from the first
         // step that is inside -- but an origin lifted by scene_epsilon off a D = 1 texel can sit just outside R and head
@@ -399,37 +408,65 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
         const float pa = fmaf(s1, da, oa), pb = fmaf(s1, db, ob), pc = fmaf(s1, dc, oc);
         go = fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f;
     }
-    int ka = 0;
-    while (go) {
-        float rowB, colB, q2B;
-        PROF_BEGIN(6);
-        seg_setup<STATS>(f, oa, ob, oc, da, db, dc, rq, ka, rowA, colA, q2A, sg, rowB, colB, q2B, cnt);
-        PROF_END(6);
-        PROF_BEGIN(7);
-        if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, 1, sg.jlo - 1);
-        if (__ballot(sg.exact) != 0ull)
-            step_loop<WIDE, PRIMARY, STATS, true, 1>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
-        else
-            step_loop<WIDE, PRIMARY, STATS, false, BATCH>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
-        PROF_END(7);
+    return go;
+}
+template <bool PRIMARY>
+__device__ __forceinline__ bool march_begin(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                            MarchState& m) {
+    float q2;
+    exact_rowcol(f, oa, ob, oc, m.rowA, m.colA, q2);
+    return march_begin_at<PRIMARY>(f, oa, ob, oc, da, db, dc, m);
+}
+
+// ONE 16-step segment of a march (the lanes that call it are still marching): anchors + skip interval, the steps
+// that can be at/below the surface, the termination test at the segment end.  `hit` / `sk_hit` are set by the step
+// that lands at/below the surface, `go` says whether the ray continues with the next segment.
+template <bool WIDE, bool PRIMARY, bool STATS, int BATCH>
+__device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, float smax, Seg& sg, bool& go, bool& hit,
+                                              float& sk_hit, uint32_t* cnt) {
+    const float oa = m.oa, ob = m.ob, oc = m.oc, da = m.da, db = m.db, dc = m.dc;
+    const int ka = m.ka;
+    float rowB, colB, q2B;
+    PROF_BEGIN(6);
+    seg_setup<STATS>(f, oa, ob, oc, da, db, dc, m.rq, ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
+    PROF_END(6);
+    PROF_BEGIN(7);
+    if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, 1, sg.jlo - 1);
+    if (__ballot(sg.exact) != 0ull)
+        step_loop<WIDE, PRIMARY, STATS, true, 1>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+    else
+        step_loop<WIDE, PRIMARY, STATS, false, BATCH>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+    PROF_END(7);
 #ifdef MRTX_PROF
 #ifndef MRTX_PROF_SPREAD
-        cnt[8] += 1;                                     // wave-level segments
-        cnt[9] += (uint32_t)__popcll(__ballot(true));    // lanes alive in them
-        cnt[PRIMARY ? 13 : 14] += (__ballot(sg.jlo <= sg.jhi) == 0ull) ? 1u : 0u;   // wave-level segments nobody steps in
-        cnt[15] += PRIMARY ? 1u : 0u;
+    cnt[8] += 1;                                     // wave-level segments
+    cnt[9] += (uint32_t)__popcll(__ballot(true));    // lanes alive in them
+    cnt[PRIMARY ? 13 : 14] += (__ballot(sg.jlo <= sg.jhi) == 0ull) ? 1u : 0u;   // wave-level segments nobody steps in
+    cnt[15] += PRIMARY ? 1u : 0u;
 #endif
 #endif
-        if (go) {
-            // still marching after the last evaluated step: did the ray end inside the skipped tail?
-            if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, max(sg.jhi + 1, 1), SEG_N);
-            const int k = ka + SEG_N;
-            const float sk = (float)k * f.step;
-            const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
-            go = (PRIMARY ? (sk <= smax) : (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f)) & (k < f.kmax);
-        }
-        ka += SEG_N; rowA = rowB; colA = colB; q2A = q2B;
+    if (go) {
+        // still marching after the last evaluated step: did the ray end inside the skipped tail?
+        if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, max(sg.jhi + 1, 1), SEG_N);
+        const int k = ka + SEG_N;
+        const float sk = (float)k * f.step;
+        const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
+        go = (PRIMARY ? (sk <= smax) : (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f)) & (k < f.kmax);
     }
+    m.ka = ka + SEG_N; m.rowA = rowB; m.colA = colB; m.q2A = q2B;
+}
+
+// Coarse march s_k = k*step, k = 1, 2, ...; returns true and s_k at the first sample at/below the surface.
+// PRIMARY: stop when s_k > smax (left the bounding sphere); shadow rays: stop when r^2 > R^2.
+// A lane drops out of the exec mask when it hits or leaves, and the wave leaves the loop when no lane is still
+// marching.  f.kmax is a multiple of SEG_N.
+template <bool WIDE, bool PRIMARY, bool STATS, int BATCH>
+__device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                      float smax, Seg& sg, float& sk_hit, uint32_t* cnt) {
+    MarchState m;
+    bool hit = false;
+    bool go = march_begin<PRIMARY>(f, oa, ob, oc, da, db, dc, m);
+    while (go) march_segment<WIDE, PRIMARY, STATS, BATCH>(f, m, smax, sg, go, hit, sk_hit, cnt);
     return hit;
 }
 
@@ -543,12 +580,13 @@ __device__ __forceinline__ void hit_vertex(const FrameC& f, float ha, float hb, 
     }
 }
 
-// D5: one sample of the spherical light from a vertex, shadow ray marched through the same height field;
-// returns radiance * solid angle / pi * cos(theta_i) * visibility
-template <bool STATS, bool WIDE, int BATCH>
-__device__ __forceinline__ float direct_light(const FrameC& f, const Vertex& v, float u2, float u3, uint32_t* cnt) {
+// D5: one sample of the spherical light from a vertex: the shadow ray (origin lifted by scene_epsilon, direction
+// uniform in the cone the light subtends) and what it carries if it arrives, radiance * solid angle / pi * cos(theta_i);
+// false when the sampled direction lies below the surface (no shadow ray, no contribution).
+__device__ __forceinline__ bool light_sample(const FrameC& f, const Vertex& v, float u2, float u3, float& oa, float& ob,
+                                             float& oc, float& wa, float& wb, float& wc, float& carried) {
     const float eps = CF(f)->scene_eps;
-    const float oa = fmaf(eps, v.na, v.pa), ob = fmaf(eps, v.nb, v.pb), oc = fmaf(eps, v.nc, v.pc);
+    oa = fmaf(eps, v.na, v.pa); ob = fmaf(eps, v.nb, v.pb); oc = fmaf(eps, v.nc, v.pc);
     const float ta = CF(f)->Lb[0] - oa, tb = CF(f)->Lb[1] - ob, tc = CF(f)->Lb[2] - oc;
     const float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
     const float inv_dist = 1.0f / sqrtf(d2);
@@ -565,16 +603,94 @@ __device__ __forceinline__ float direct_light(const FrameC& f, const Vertex& v, 
     float b1a, b1b, b1c, b2a, b2b, b2c;
     duff_basis(la, lb, lc, b1a, b1b, b1c, b2a, b2b, b2c);
     const float ca = sint * cph, sa = sint * sph;
-    const float wa = fmaf(cost, la, fmaf(sa, b2a, ca * b1a));
-    const float wb = fmaf(cost, lb, fmaf(sa, b2b, ca * b1b));
-    const float wc = fmaf(cost, lc, fmaf(sa, b2c, ca * b1c));
+    wa = fmaf(cost, la, fmaf(sa, b2a, ca * b1a));
+    wb = fmaf(cost, lb, fmaf(sa, b2b, ca * b1b));
+    wc = fmaf(cost, lc, fmaf(sa, b2c, ca * b1c));
     const float cosi = fmaf(v.nc, wc, fmaf(v.nb, wb, v.na * wa));
-    if (!(cosi > 0.0f)) return 0.0f;
+    carried = (CF(f)->rad2 * omc) * cosi;
+    return cosi > 0.0f;
+}
+
+// the light sample with its shadow ray marched through the same height field: carried radiance * visibility
+template <bool STATS, bool WIDE, int BATCH>
+__device__ __forceinline__ float direct_light(const FrameC& f, const Vertex& v, float u2, float u3, uint32_t* cnt) {
+    float oa, ob, oc, wa, wb, wc, carried;
+    if (!light_sample(f, v, u2, u3, oa, ob, oc, wa, wb, wc, carried)) return 0.0f;
     if (STATS) cnt[ST_SHADOW]++;
     Seg ssg;
     float sk_occ;
     if (march<WIDE, false, STATS, BATCH>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return 0.0f;
-    return (CF(f)->rad2 * omc) * cosi;
+    return carried;
+}
+
+// D6: what happens to a path after the direct term of its vertex number `seg` (camera segment = 1): stop at
+// path_seg_max, Russian roulette beyond path_seg_min, else the cosine-weighted continuation ray from the lifted
+// vertex.  Returns false when the path ends; thr is the path throughput (updated).
+__device__ __forceinline__ bool continue_path(const FrameC& f, const Vertex& v, uint32_t ks, uint32_t seg, float& t0r,
+                                              float& t1r, float& t2r, float& boa, float& bob, float& boc, float& bda,
+                                              float& bdb, float& bdc) {
+    if (seg >= CF(f)->path_seg_max) return false;
+    // segment seg+1: cosine-weighted direction about the normal => throughput *= albedo
+    const uint32_t d0 = 4u + 5u * (seg - 1u);
+    t0r *= v.al0; t1r *= v.al1; t2r *= v.al2;
+    if (seg + 1u > CF(f)->path_seg_min) {   // Russian roulette beyond the guaranteed segments
+        float pcont = v.al0 > v.al1 ? v.al0 : v.al1;
+        pcont = pcont > v.al2 ? pcont : v.al2;
+        pcont = pcont > 1.0f ? 1.0f : pcont;
+        if (!(u01(ks, d0) < pcont)) return false;
+        const float ip = 1.0f / pcont;
+        t0r *= ip; t1r *= ip; t2r *= ip;
+    }
+    const float uh1 = u01(ks, d0 + 1u), uh2 = u01(ks, d0 + 2u);
+    const float rr = sqrtf(uh1), zz = sqrtf(1.0f - uh1);
+    float cph, sph;
+    sincos_turn(uh2, cph, sph);
+    float b1a, b1b, b1c, b2a, b2b, b2c;
+    duff_basis(v.na, v.nb, v.nc, b1a, b1b, b1c, b2a, b2b, b2c);
+    const float xx = rr * cph, yy = rr * sph;
+    const float eps = CF(f)->scene_eps;
+    boa = fmaf(eps, v.na, v.pa); bob = fmaf(eps, v.nb, v.pb); boc = fmaf(eps, v.nc, v.pc);
+    bda = fmaf(zz, v.na, fmaf(yy, b2a, xx * b1a));
+    bdb = fmaf(zz, v.nb, fmaf(yy, b2b, xx * b1b));
+    bdc = fmaf(zz, v.nc, fmaf(yy, b2c, xx * b1c));
+    return true;
+}
+
+// A continuation ray that left the Moon: the flat Sun-disk sphere IS visible to it (the reference keeps the light the
+// disk bounces onto the Moon small through its radiance 2.0 and by parking it, moon_renderer.py:109-111, :757-760),
+// then the environment texel along its direction; adds throughput x radiance.  Moon frame, float32: distance of the
+// disk centre from the ray.
+template <bool STATS>
+__device__ __forceinline__ bool escaped_radiance(const FrameC& f, float boa, float bob, float boc, float bda, float bdb,
+                                                 float bdc, float& e0, float& e1, float& e2, uint32_t* cnt) {
+    if (CF(f)->sun_on) {
+        const float sa = CF(f)->Sb[0] - boa, sb = CF(f)->Sb[1] - bob, sc = CF(f)->Sb[2] - boc;
+        const float bq = fmaf(sc, bdc, fmaf(sb, bdb, sa * bda));
+        const float qa = fmaf(-bq, bda, sa), qb = fmaf(-bq, bdb, sb), qc = fmaf(-bq, bdc, sc);
+        const float d2 = fmaf(qc, qc, fmaf(qb, qb, qa * qa));
+        if (bq > 0.0f && d2 < CF(f)->sun_r2) {
+            e0 = e1 = e2 = CF(f)->sun_rad;
+            if (STATS) cnt[ST_SUNHIT]++;
+            return true;
+        }
+    }
+    if (CF(f)->bg) {   // environment radiance along its direction (scene frame)
+        const float ex = fmaf(bdc, CF(f)->Mf[2][0], fmaf(bdb, CF(f)->Mf[1][0], bda * CF(f)->Mf[0][0]));
+        const float ey = fmaf(bdc, CF(f)->Mf[2][1], fmaf(bdb, CF(f)->Mf[1][1], bda * CF(f)->Mf[0][1]));
+        const float ez = fmaf(bdc, CF(f)->Mf[2][2], fmaf(bdb, CF(f)->Mf[1][2], bda * CF(f)->Mf[0][2]));
+        env_lookup<STATS>(f, ex, ey, ez, e0, e1, e2, cnt);
+        return true;
+    }
+    return false;
+}
+template <bool STATS>
+__device__ __forceinline__ void escaped_path(const FrameC& f, float boa, float bob, float boc, float bda, float bdb,
+                                             float bdc, float t0r, float t1r, float t2r, float& c0, float& c1,
+                                             float& c2, uint32_t* cnt) {
+    float e0, e1, e2;
+    if (escaped_radiance<STATS>(f, boa, bob, boc, bda, bdb, bdc, e0, e1, e2, cnt)) {
+        c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
+    }
 }
 
 // D11: nearest overlay capsule of this tile's bin along the primary ray.  ro = ray point closest to the Moon
@@ -636,11 +752,19 @@ __device__ __forceinline__ float nearest_capsule(const FrameC& f, int lt, float 
 struct SampleOut {
     float c0, c1, c2, hitflag;
     float h0, h1, h2, h3;
+    // DEFER: the continuation ray of the path (origin, direction, throughput, exact texel coordinates of the origin)
+    // and the sample's RNG key, for path_kernel
+    float oa, ob, oc, da, db, dc, t0, t1, t2, row, col;
+    uint32_t ks;
+    bool path;
 };
 
-template <bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
+// MODE: 0 = direct light only, 1 = the whole path inside this wave (BOUNCE), 2 = direct light + hand-over of the
+// vertex to path_kernel (DEFER)
+template <bool STATS, bool WIDE, int MODE, bool OVERLAY>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
+    constexpr bool BOUNCE = MODE == 1, DEFER = MODE == 2;
     constexpr int BATCH = BOUNCE ? MRTX_STEP_BATCH_BOUNCE : MRTX_STEP_BATCH;   // incoherent bounce rays waste the speculative fetches
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
     const uint32_t kp = mix32(pix + CF(f)->key0);
@@ -648,6 +772,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     const float u0 = u01(ks, 0), u1 = u01(ks, 1), u2 = u01(ks, 2), u3 = u01(ks, 3);
     o.c0 = o.c1 = o.c2 = 0.0f; o.hitflag = 0.0f;
     o.h0 = o.h1 = o.h2 = o.h3 = 0.0f;
+    o.path = false;
     if (STATS) cnt[ST_PRIMARY]++;
     PROF_BEGIN(1);
 
@@ -789,45 +914,29 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         o.c0 = fmaf(t0r * v.al0, wgt, o.c0);
         o.c1 = fmaf(t1r * v.al1, wgt, o.c1);
         o.c2 = fmaf(t2r * v.al2, wgt, o.c2);
-        if (!BOUNCE || seg >= CF(f)->path_seg_max) break;
-        // segment seg+1: cosine-weighted direction about the normal => throughput *= albedo
-        const uint32_t d0 = 4u + 5u * (seg - 1u);
-        t0r *= v.al0; t1r *= v.al1; t2r *= v.al2;
-        if (seg + 1u > CF(f)->path_seg_min) {   // Russian roulette beyond the guaranteed segments
-            float pcont = v.al0 > v.al1 ? v.al0 : v.al1;
-            pcont = pcont > v.al2 ? pcont : v.al2;
-            pcont = pcont > 1.0f ? 1.0f : pcont;
-            if (!(u01(ks, d0) < pcont)) break;
-            const float ip = 1.0f / pcont;
-            t0r *= ip; t1r *= ip; t2r *= ip;
+        if (DEFER) {
+            // The path goes on in path_kernel.  What is still coherent -- the 64 samples of a pixel decide together
+            // whether to continue, build their continuation rays and locate the ray origins on the DEM grid -- is done
+            // here at full occupancy; the queue record is a ray that is ready to march.
+            if (continue_path(f, v, ks, 1u, t0r, t1r, t2r, o.oa, o.ob, o.oc, o.da, o.db, o.dc)) {
+                float q2;
+                exact_rowcol(f, o.oa, o.ob, o.oc, o.row, o.col, q2);
+                o.t0 = t0r; o.t1 = t1r; o.t2 = t2r;
+                o.ks = ks;
+                o.path = true;
+                if (STATS) cnt[ST_BOUNCE]++;
+            }
         }
-        const float uh1 = u01(ks, d0 + 1u), uh2 = u01(ks, d0 + 2u);
+        if (!BOUNCE) break;
+        float boa, bob, boc, bda, bdb, bdc;
+        if (!continue_path(f, v, ks, seg, t0r, t1r, t2r, boa, bob, boc, bda, bdb, bdc)) break;
+        const uint32_t d0 = 4u + 5u * (seg - 1u);
         ul1 = u01(ks, d0 + 3u); ul2 = u01(ks, d0 + 4u);
-        const float rr = sqrtf(uh1), zz = sqrtf(1.0f - uh1);
-        float cph, sph;
-        sincos_turn(uh2, cph, sph);
-        float b1a, b1b, b1c, b2a, b2b, b2c;
-        duff_basis(v.na, v.nb, v.nc, b1a, b1b, b1c, b2a, b2b, b2c);
-        const float xx = rr * cph, yy = rr * sph;
-        const float eps = CF(f)->scene_eps;
-        const float boa = fmaf(eps, v.na, v.pa), bob = fmaf(eps, v.nb, v.pb), boc = fmaf(eps, v.nc, v.pc);
-        const float bda = fmaf(zz, v.na, fmaf(yy, b2a, xx * b1a));
-        const float bdb = fmaf(zz, v.nb, fmaf(yy, b2b, xx * b1b));
-        const float bdc = fmaf(zz, v.nc, fmaf(yy, b2c, xx * b1c));
         if (STATS) cnt[ST_BOUNCE]++;
         Seg bsg;
         float bhi = 0.0f;
         if (!march<WIDE, false, STATS, BATCH>(f, boa, bob, boc, bda, bdb, bdc, 0.0f, bsg, bhi, cnt)) {
-            if (CF(f)->bg) {   // the path leaves the Moon: environment radiance along its direction (scene frame)
-                const float ex = fmaf(bdc, CF(f)->Mf[2][0], fmaf(bdb, CF(f)->Mf[1][0], bda * CF(f)->Mf[0][0]));
-                const float ey = fmaf(bdc, CF(f)->Mf[2][1], fmaf(bdb, CF(f)->Mf[1][1], bda * CF(f)->Mf[0][1]));
-                const float ez = fmaf(bdc, CF(f)->Mf[2][2], fmaf(bdb, CF(f)->Mf[1][2], bda * CF(f)->Mf[0][2]));
-                float e0, e1, e2;
-                env_lookup<STATS>(f, ex, ey, ez, e0, e1, e2, cnt);
-                o.c0 = fmaf(t0r, e0, o.c0);
-                o.c1 = fmaf(t1r, e1, o.c1);
-                o.c2 = fmaf(t2r, e2, o.c2);
-            }
+            escaped_path<STATS>(f, boa, bob, boc, bda, bdb, bdc, t0r, t1r, t2r, o.c0, o.c1, o.c2, cnt);
             break;
         }
         const int bk = (int)rintf(bhi * f.inv_step);
@@ -875,9 +984,10 @@ __device__ __forceinline__ float tree_sum(float v) {
 // OVERLAY>) miscomputed a sample with no undefined behaviour the compiler could name.  They only render the counted
 // frame, so they get the registers they ask for.
 #define MRTX_BOUNCE_WAVES(STATS) ((STATS) ? 2 : MRTX_MIN_WAVES_BOUNCE)
-template <int S, bool STATS, bool WIDE, bool BOUNCE, bool OVERLAY>
-__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, BOUNCE ? MRTX_BOUNCE_WAVES(STATS) : MRTX_MIN_WAVES)
-render_kernel(const FrameC f) {
+template <int S, bool STATS, bool WIDE, int MODE, bool OVERLAY>
+__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MODE == 1 ? MRTX_BOUNCE_WAVES(STATS) : MRTX_MIN_WAVES)
+render_kernel(const FrameC f, const PathQ pq) {
+    constexpr bool DEFER = MODE == 2;
     constexpr int P = 64 / S;
     constexpr int PW = P >= 64 ? 8 : P >= 32 ? 8 : P >= 16 ? 4 : P >= 8 ? 4 : P >= 4 ? 2 : P >= 2 ? 2 : 1;
     constexpr int PH = P / PW;
@@ -944,14 +1054,30 @@ render_kernel(const FrameC f) {
         }
         SampleOut o;
         o.h0 = o.h1 = o.h2 = o.h3 = 0.f;
-        for (uint32_t blk = 0; blk < f.n_blocks; blk++) {
+        o.path = false;
+        o.oa = o.ob = o.oc = o.da = o.db = o.dc = o.t0 = o.t1 = o.t2 = o.row = o.col = 0.f; o.ks = 0u;
+        bool deferred = false;
+        for (uint32_t blk = 0; blk < f.n_blocks; blk++) {   // DEFER launches carry one block each
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
             PROF_BEGIN(0);
-            if (inb) trace_sample<STATS, WIDE, BOUNCE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            if (inb) trace_sample<STATS, WIDE, MODE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
             PROF_END(0);
-            s0 += tree_sum<S>(o.c0);
-            s1 += tree_sum<S>(o.c1);
-            s2 += tree_sum<S>(o.c2);
+            if (DEFER) deferred = __ballot(o.path) != 0ull;
+            if (DEFER && deferred) {
+                // Some path of this wave continues: every lane hands its sample to path_kernel / resolve_paths_kernel
+                // (the radiance sum of a pixel needs all S final values, in the spec's order); coverage is final now.
+                const uint32_t chunk = (uint32_t)blockIdx.x * (uint32_t)NJOBS + (uint32_t)job;
+                const uint32_t e = chunk * 64u + (uint32_t)lane;
+                pq.ray0[e] = make_float4(o.path ? o.oa : MRTX_NO_PATH, o.ob, o.oc, o.da);
+                pq.ray1[e] = make_float4(o.db, o.dc, o.t0, o.t1);
+                pq.ray2[e] = make_float4(o.t2, o.row, o.col, __uint_as_float(o.ks));
+                pq.c0[e] = o.c0; pq.c1[e] = o.c1; pq.c2[e] = o.c2;
+                if (lane == 0) pq.meta[chunk] = 0x80000000u | (uint32_t)(px0 + jx * PW) | ((uint32_t)(py0 + jy * PH) << 15);
+            } else {
+                s0 += tree_sum<S>(o.c0);
+                s1 += tree_sum<S>(o.c1);
+                s2 += tree_sum<S>(o.c2);
+            }
             s3 += tree_sum<S>(o.hitflag);
         }
         if (inb && s == 0) {
@@ -977,6 +1103,296 @@ render_kernel(const FrameC f) {
         }
         __syncthreads();
         if (threadIdx.x < ST_N) atomicAdd(&f.stats[threadIdx.x], (unsigned long long)lds_cnt[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// D6 behind a queue: everything after the first vertex of a path (set_uint("path_seg_range", 2, 4),
+// moon_renderer.py:583).
+//
+// Why not inside render_kernel: a continuation ray is cosine-distributed about the normal and leaves the shell after
+// ~11/sin(elevation) steps -- mean 1.4 segments, but the longest of the 64 rays of a pixel needs 9-10 -- and the
+// few paths that hit terrain again (~8 %) drag the wave through bisection, vertex, shadow march and the next bounce at
+// that lane occupancy.  Here a wave is PERSISTENT and keeps 64 marches in flight whatever path they belong to: every
+// lane is a little state machine, a lane whose path is finished takes the next record of the wave's share of the
+// queue -- a ray that is ready to march: render_kernel has already decided to continue, built the ray and located its
+// origin on the DEM grid while the 64 samples of the pixel were still together --, and the rare heavy steps (a
+// continuation ray that hit terrain: bisection + vertex + light sample; a vertex that got its direct term: roulette +
+// next ray) wait until enough lanes need them.  Shadow and continuation rays share the one segment loop.  No workgroup
+// barrier, no atomics on the data path: wave w of NW owns chunks w, w + NW, ... of the render launch (NW is a
+// multiple of 8, so the chunks a wave reads were written by render_kernel blocks of its own XCD, and the waves of
+// an XCD walk neighbouring pixels of one tile at a time).
+// Every arithmetic step is the one trace_sample<MODE 1> performs for the same (pixel, sample), in the same order, so
+// the three implementations (this, the in-wave loop, the oracle) agree bit for bit.
+#ifndef MRTX_PATH_WAVES
+#define MRTX_PATH_WAVES 5
+#endif
+#ifndef MRTX_PATH_BATCH
+#define MRTX_PATH_BATCH MRTX_STEP_BATCH_BOUNCE
+#endif
+#ifdef MRTX_PATH_PROF   // measurement build only (tools/path_prof.py): block executions and lane counts of path_kernel
+__device__ unsigned long long g_pprof[16];
+#endif
+enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_ENDED, PS_HITWAIT, PS_SHADE };
+
+// The march inside path_kernel is cut at STEP granularity, not at segment granularity: within one 16-step segment
+// the rays of a wave need anything from 0 to 16 dependent DEM fetches (mean ~4), and a wave that steps a whole
+// segment per iteration waits for its slowest lane -- up to 16 memory round trips per iteration (measured: 17.6 ms
+// for the path stage, nearly inversely proportional to the number of waves in flight: pure latency).  So a lane is in
+// one of two march states: NEEDSEG (the next segment's anchors, quadratic and skip interval are to be set up: ~300
+// VALU + the max-mip fetch) and STEP (its next step of the current segment is to be evaluated: ~45 VALU + one DEM
+// fetch); every iteration evaluates ONE step for all stepping lanes, and the set-up block runs when enough lanes
+// need it (or nobody is stepping).  Same evaluations, same order per ray as march_segment().
+template <bool STATS, bool WIDE>
+__global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(const FrameC f, const PathQ pq) {
+    const uint32_t lane = threadIdx.x;
+    // Work distribution.  The records of render block b (b % 8 = a group label: blocks with one label ran on one XCD and
+    // cover neighbouring pixels of the same tiles, see the remap in render_kernel) are taken in GROUPS of G consecutive
+    // blocks of one label, handed out by atomic counters in device memory -- one set of counters per XCD of THIS
+    // kernel (HW_REG_XCC_ID), so that at any time the ~640 waves of an XCD march rays that start within about one
+    // 32x32-pixel tile of each other and share its DEM neighbourhood in that XCD's L2.  (A static deal -- wave w owns
+    // chunks w, w + NW, ... -- lets the waves drift apart by dozens of tiles: 46 % L2 hits, 80 GB of HBM reads.)
+    // Which wave marches which ray has no influence on any result.
+    const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+    const uint32_t sub = (blockIdx.x >> 3) % (uint32_t)pq.n_sub;
+    uint32_t* const ctr = pq.counters + xcd * (uint32_t)pq.n_sub + sub;
+    const uint32_t npos = (pq.grid_a + 7u) >> 3;                     // render blocks per label
+    const uint32_t grp_recs = 64u << (pq.grp_log2 + pq.njobs_log2);   // records in a group
+    uint32_t grp_first = 0, grp_used = grp_recs;                      // first block position of the current group; records taken
+    bool more = npos > 0;                                             // groups may be left
+    uint32_t cnt[ST_N];
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_N; i++) cnt[i] = 0;
+    }
+#ifdef MRTX_PATH_PROF
+    uint32_t pf[16];   // wave-uniform: iterations, then (executions, lanes) of refill / set-up / step / rare
+#pragma unroll
+    for (int i = 0; i < 16; i++) pf[i] = 0;
+#endif
+
+    // per-lane path state
+    int state = PS_IDLE;
+    bool shadow = false;          // which ray the lane is marching: the shadow ray of its vertex or the continuation ray
+    bool hit = false, have_c = false;
+    uint32_t e = 0, ks = 0, seg = 1;
+    MarchState m;
+    Seg sg;
+    int j = 1;                    // next step of the current segment (STEP lanes)
+    float sk_hit = 0.0f;
+    Vertex v;
+    float t0r = 1.0f, t1r = 1.0f, t2r = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, carried = 0.0f, wgt = 0.0f;
+    m.oa = m.ob = m.oc = m.da = m.db = m.dc = 0.0f; m.rq.q0 = m.rq.b = m.rq.a = 0.0f; m.rowA = m.colA = m.q2A = 0.0f; m.ka = 0;
+    sg.sa = sg.ra = sg.r1 = sg.r2 = sg.ca = sg.c1 = sg.c2 = 0.0f; sg.jlo = 1; sg.jhi = 0; sg.exact = false;
+    v.pa = v.pb = v.pc = v.na = v.nb = v.nc = v.al0 = v.al1 = v.al2 = 0.0f;
+
+    for (;;) {
+        // Every lane waits for exactly one of four blocks -- refill, segment set-up, step, rare -- and the wave decides
+        // per iteration which of them to run (wave-uniform flags), so that the expensive ones execute with many lanes:
+        // stepping is cheap and runs whenever a lane can step; the others wait for their thresholds, or until nothing
+        // cheaper can make progress.
+        const uint64_t idle_m = __ballot(state == PS_IDLE);
+        const int nidle = __popcll(idle_m);
+        const bool can_refill = more;
+        const int n_seg = __popcll(__ballot(state == PS_NEEDSEG)), n_step = __popcll(__ballot(state == PS_STEP));
+        const int n_rare = __popcll(__ballot(state == PS_HITWAIT || state == PS_SHADE));
+        bool do_refill, do_seg, do_step, do_rare;
+        if (pq.policy == 0) {
+            do_step = n_step > 0;
+            do_seg = n_seg > 0 && (n_seg >= pq.seg_min || n_step == 0);
+            do_refill = can_refill && nidle > 0 && (nidle >= pq.refill_min || (n_step == 0 && !do_seg));
+            do_rare = n_rare > 0 && (n_rare >= pq.rare_min || (n_step == 0 && !do_seg && !do_refill));
+        } else {   // greedy: only the block most lanes wait for
+            const int sc_refill = can_refill && nidle > 0 ? nidle + pq.refill_min : -1000, sc_seg = n_seg > 0 ? n_seg + pq.seg_min : -1000;
+            const int sc_step = n_step > 0 ? n_step : -1000, sc_rare = n_rare > 0 ? n_rare + pq.rare_min : -1000;
+            const int best = max(max(sc_refill, sc_seg), max(sc_step, sc_rare));
+            do_step = sc_step == best;
+            do_seg = !do_step && sc_seg == best;
+            do_refill = !do_step && !do_seg && sc_refill == best;
+            do_rare = !do_step && !do_seg && !do_refill && sc_rare == best;
+        }
+#ifdef MRTX_PATH_PROF
+        pf[0]++;
+        if (do_refill) { pf[1]++; pf[2] += (uint32_t)nidle; }
+        if (do_seg) { pf[3]++; pf[4] += (uint32_t)n_seg; }
+        if (do_step) { pf[5]++; pf[6] += (uint32_t)n_step; }
+        if (do_rare) { pf[7]++; pf[8] += (uint32_t)n_rare; }
+#endif
+
+        bool segend = false;
+        if (do_refill) {
+            // ---- refill: idle lanes take the next records of the wave's current group (a new group when it is used up)
+            if (grp_used >= grp_recs) {
+                uint32_t g = 0;
+                if (lane == 0) g = atomicAdd(ctr, 1u);
+                g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+                grp_first = (g * (uint32_t)pq.n_sub + sub) << pq.grp_log2;
+                grp_used = 0;
+                more = grp_first < npos;
+            }
+            if (more) {
+                if (state == PS_IDLE) {
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                    const uint32_t vi = grp_used + r;
+                    const uint32_t blk = ((grp_first + (vi >> (6 + pq.njobs_log2))) << 3) + (blockIdx.x & 7u);
+                    if (vi < grp_recs && blk < pq.grid_a) {
+                        const uint32_t chunk = (blk << pq.njobs_log2) + ((vi >> 6) & ((1u << pq.njobs_log2) - 1u));
+                        e = chunk * 64u + (vi & 63u);
+                        // one round of loads: the record is read whether or not its chunk was deferred (the arrays
+                        // cover every chunk; an undeferred chunk holds stale values that are never used)
+                        const uint32_t mt = pq.meta[chunk];
+                        const float4 r0 = pq.ray0[e], r1 = pq.ray1[e], r2 = pq.ray2[e];
+                        if ((mt & 0x80000000u) && r0.x < 0.5f * MRTX_NO_PATH) {
+                            m.rowA = r2.y; m.colA = r2.z;
+                            const bool go = march_begin_at<false>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m);
+                            t0r = r1.z; t1r = r1.w; t2r = r2.x;
+                            ks = __float_as_uint(r2.w);
+                            hit = false; shadow = false; have_c = false;
+                            seg = 1;
+                            state = go ? PS_NEEDSEG : PS_ENDED;
+                        }
+                    }
+                }
+                grp_used += (uint32_t)nidle;
+            }
+        }
+        if (do_seg) {
+            // ---- segment set-up for the lanes that need one
+            if (state == PS_NEEDSEG) {
+                float rowB, colB, q2B;
+                seg_setup<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, m.rq, m.ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
+                if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, 1, sg.jlo - 1);
+                m.rowA = rowB; m.colA = colB; m.q2A = q2B;   // the next segment starts where this one ends
+                j = sg.jlo;
+                if (j <= sg.jhi) state = PS_STEP; else segend = true;
+            }
+        }
+        if (do_step) {
+            // ---- ONE step for every stepping lane
+            if (state == PS_STEP) {
+                const int k = m.ka + j;
+                const float sk = (float)k * f.step;
+                const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
+                const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+                const bool in = (r2 <= f.R2f) & (k <= f.kmax);
+                const bool bel = below_seg<WIDE, true>(f, sg, sk, pa, pb, pc, r2);
+                if (STATS) { cnt[ST_HEIGHT] += in ? 1u : 0u; cnt[ST_FETCH]++; }
+                j++;
+                if (in & bel) { hit = true; sk_hit = sk; state = PS_ENDED; }
+                else if (!in) state = PS_ENDED;
+                else if (j > sg.jhi) segend = true;
+            }
+        }
+
+        // ---- end of a segment that is neither hit nor left: did the ray end inside the skipped tail?
+        if (segend) {
+            if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, max(sg.jhi + 1, 1), SEG_N);
+            const int k = m.ka + SEG_N;
+            const float sk = (float)k * f.step;
+            const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
+            const bool go = (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f) & (k < f.kmax);
+            m.ka = k;
+            state = go ? PS_NEEDSEG : PS_ENDED;
+        }
+
+        // ---- march over
+        if (state == PS_ENDED) {
+            if (shadow) {
+                wgt = hit ? 0.0f : carried;
+                state = PS_SHADE;
+            } else if (hit) {
+                state = PS_HITWAIT;
+            } else {
+                // the path left the Moon: Sun disk / environment along the ray, if there is any
+                float e0, e1, e2;
+                if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {
+                    if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                    c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
+                }
+                if (have_c) { pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2; }
+                state = PS_IDLE;
+            }
+        }
+
+        // ---- the rare steps (~8 % of the paths reach them): a continuation ray that hit terrain gets its vertex and
+        // light sample (~600 VALU); a vertex whose shadow ray is through gets its direct term, and the path is
+        // continued or ended (~250 VALU).  They wait until enough lanes need them -- or nothing is marching.
+        if (do_rare) {
+            if (state == PS_HITWAIT) {
+                if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                const int bk = (int)rintf(sk_hit * f.inv_step);
+                float blo = (float)(bk - 1) * f.step, bhi = sk_hit;
+                refine<WIDE>(f, sg, m.oa, m.ob, m.oc, m.da, m.db, m.dc, blo, bhi);
+                if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
+                hit_vertex<STATS, WIDE>(f, fmaf(blo, m.da, m.oa), fmaf(blo, m.db, m.ob), fmaf(blo, m.dc, m.oc), v, cnt);
+                seg++;
+                const uint32_t d0 = 4u + 5u * (seg - 2u);   // the dimensions drawn when this segment was started
+                const float ul1 = u01(ks, d0 + 3u), ul2 = u01(ks, d0 + 4u);
+                float soa, sob, soc, swa, swb, swc;
+                if (light_sample(f, v, ul1, ul2, soa, sob, soc, swa, swb, swc, carried)) {
+                    if (STATS) cnt[ST_SHADOW]++;
+                    const bool go = march_begin<false>(f, soa, sob, soc, swa, swb, swc, m);
+                    hit = false; shadow = true;
+                    state = go ? PS_NEEDSEG : PS_ENDED;
+                } else {
+                    wgt = 0.0f;
+                    state = PS_SHADE;
+                }
+            }
+            if (state == PS_SHADE) {
+                c0 = fmaf(t0r * v.al0, wgt, c0);
+                c1 = fmaf(t1r * v.al1, wgt, c1);
+                c2 = fmaf(t2r * v.al2, wgt, c2);
+                float boa, bob, boc, bda, bdb, bdc;
+                if (continue_path(f, v, ks, seg, t0r, t1r, t2r, boa, bob, boc, bda, bdb, bdc)) {
+                    if (STATS) cnt[ST_BOUNCE]++;
+                    const bool go = march_begin<false>(f, boa, bob, boc, bda, bdb, bdc, m);
+                    hit = false; shadow = false;
+                    state = go ? PS_NEEDSEG : PS_ENDED;
+                } else {
+                    pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2;
+                    state = PS_IDLE;
+                }
+            }
+        }
+    }
+
+#ifdef MRTX_PATH_PROF
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) atomicAdd(&g_pprof[i], (unsigned long long)pf[i]);
+    }
+#endif
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_N; i++) {
+            uint32_t t = cnt[i];
+#pragma unroll
+            for (int k = 1; k < 64; k <<= 1) t += __shfl_xor(t, k, 64);
+            if (lane == 0 && t != 0u) atomicAdd(&f.stats[i], (unsigned long long)t);
+        }
+    }
+}
+
+// The radiance sums of the deferred pixels: the S final sample values of a pixel added in the butterfly order of the
+// spec (block sum), then onto the running sum -- exactly what render_kernel does in registers.
+template <int S>
+__global__ void __launch_bounds__(256) resolve_paths_kernel(const FrameC f, const PathQ pq) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t chunk = blockIdx.x * 4u + wv; chunk < pq.n_chunks; chunk += gridDim.x * 4u) {
+        const uint32_t mt = pq.meta[chunk];
+        if (!(mt & 0x80000000u)) continue;
+        const uint32_t e = chunk * 64u + lane;
+        const float t0 = tree_sum<S>(pq.c0[e]), t1 = tree_sum<S>(pq.c1[e]), t2 = tree_sum<S>(pq.c2[e]);
+        const uint32_t pp = lane >> pq.s_log2, ss = lane & ((1u << pq.s_log2) - 1u);
+        const uint32_t x = (mt & 0x7FFFu) + (pp & ((1u << pq.pw_log2) - 1u));
+        const uint32_t y = ((mt >> 15) & 0x7FFFu) + (pp >> pq.pw_log2);
+        if (ss == 0u && x < (uint32_t)f.W && y < (uint32_t)f.H) {
+            float4* a = reinterpret_cast<float4*>(f.accum) + ((int64_t)y * f.W + x);
+            float4 t = *a;
+            t.x += t0; t.y += t1; t.z += t2;
+            *a = t;
+        }
     }
 }
 
@@ -1305,27 +1721,51 @@ __global__ void mip_pair_kernel(const float* __restrict__ mip, float2* __restric
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mrtx_api.hip)
 extern "C++" {
-hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, bool overlay, hipStream_t st) {
+// geometry of a render launch for S samples per pixel per wave: wave-jobs ("chunks") = grid x jobs per wave
+static void render_geometry(const FrameC& f, int S, int& xcd_share, unsigned& grid, int& njobs, int& pw_log2) {
     const int P = 64 / S;
     const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1;
     const int PH = P / PW;
     const int wgmin = MRTX_WG_WAVES > 2 ? 2 * PW : MRTX_WG_WAVES > 1 ? 2 * PH : PW;
     const int wgt = (wgmin > MRTX_WG_TILE) ? wgmin : MRTX_WG_TILE;
     const int subs = (f.tile_w / wgt) * (f.tile_h / wgt);
+    xcd_share = (MRTX_XCD_SHARE && (subs & 7) == 0 && f.n_active < MRTX_XCD_SHARE_BELOW) ? 1 : 0;   // see the remap in render_kernel
+    const int groups = xcd_share ? f.n_active : (f.n_active + 7) / 8 * 8;
+    grid = (unsigned)(groups * subs);
+    njobs = (wgt / PW) * (wgt / PH);
+    pw_log2 = PW == 8 ? 3 : PW == 4 ? 2 : PW == 2 ? 1 : 0;
+}
+// records a MODE 2 (deferred-path) launch of this frame block hands over: one per lane of every chunk
+uint64_t mrtx_path_chunks(const FrameC& f, int S, uint32_t* grid_a, int* njobs_log2) {
+    int share, njobs, pwl; unsigned grid;
+    render_geometry(f, S, share, grid, njobs, pwl);
+    if (grid_a) *grid_a = grid;
+    if (njobs_log2) *njobs_log2 = njobs == 2 ? 1 : 0;
+    return (uint64_t)grid * (uint64_t)njobs;
+}
+// mode: 0 = direct light only, 1 = whole paths inside the wave, 2 = direct light + hand-over to path_kernel (pq)
+hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, int mode, bool overlay, const PathQ* pq, hipStream_t st) {
     FrameC fr = f;
-    fr.xcd_share = (MRTX_XCD_SHARE && (subs & 7) == 0 && f.n_active < MRTX_XCD_SHARE_BELOW) ? 1 : 0;   // see the remap in render_kernel
-    const int groups = fr.xcd_share ? fr.n_active : (fr.n_active + 7) / 8 * 8;
-    const dim3 grid((unsigned)(groups * subs)), block(64 * MRTX_WG_WAVES);
+    int njobs, pwl; unsigned gx;
+    render_geometry(f, S, fr.xcd_share, gx, njobs, pwl);
+    const dim3 grid(gx), block(64 * MRTX_WG_WAVES);
     if (grid.x == 0) return hipSuccess;
+    PathQ q;
+    memset(&q, 0, sizeof q);
+    if (mode == 2) {
+        if (!pq || pq->n_chunks != (uint64_t)gx * (uint64_t)njobs || pq->grid_a != gx || (1 << pq->njobs_log2) != njobs || f.n_blocks != 1)
+            return hipErrorInvalidValue;
+        q = *pq;
+    }
     const bool wide = f.dem_wide != 0;
-#define MRTX_LAUNCH(SV, ST, WD, BN, OV) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, BN, OV>), grid, block, 0, st, fr)
-#define MRTX_CASE3(SV, BN, OV)                                                                                     \
-        if (wide) { if (stats) MRTX_LAUNCH(SV, true, true, BN, OV); else MRTX_LAUNCH(SV, false, true, BN, OV); }   \
-        else { if (stats) MRTX_LAUNCH(SV, true, false, BN, OV); else MRTX_LAUNCH(SV, false, false, BN, OV); }
-#define MRTX_CASE2(SV, BN) if (overlay) { MRTX_CASE3(SV, BN, true) } else { MRTX_CASE3(SV, BN, false) }
+#define MRTX_LAUNCH(SV, ST, WD, MD, OV) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, MD, OV>), grid, block, 0, st, fr, q)
+#define MRTX_CASE3(SV, MD, OV)                                                                                     \
+        if (wide) { if (stats) MRTX_LAUNCH(SV, true, true, MD, OV); else MRTX_LAUNCH(SV, false, true, MD, OV); }   \
+        else { if (stats) MRTX_LAUNCH(SV, true, false, MD, OV); else MRTX_LAUNCH(SV, false, false, MD, OV); }
+#define MRTX_CASE2(SV, MD) if (overlay) { MRTX_CASE3(SV, MD, true) } else { MRTX_CASE3(SV, MD, false) }
 #define MRTX_CASE(SV)                                                  \
     case SV:                                                           \
-        if (bounce) { MRTX_CASE2(SV, true) } else { MRTX_CASE2(SV, false) }   \
+        if (mode == 1) { MRTX_CASE2(SV, 1) } else if (mode == 2) { MRTX_CASE2(SV, 2) } else { MRTX_CASE2(SV, 0) }   \
         break;
     switch (S) {
         MRTX_CASE(1) MRTX_CASE(2) MRTX_CASE(4) MRTX_CASE(8) MRTX_CASE(16) MRTX_CASE(32) MRTX_CASE(64)
@@ -1338,12 +1778,64 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, bool bounce, b
     return hipGetLastError();
 }
 
+// persistent waves the device holds at once for path_kernel (a multiple of 8: see the chunk deal in the kernel)
+int mrtx_path_waves(bool stats, bool wide, int* out) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+#define MRTX_OCC(ST, WD) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrtx::path_kernel<ST, WD>, 64, 0)
+    if (stats) e = wide ? MRTX_OCC(true, true) : MRTX_OCC(true, false);
+    else e = wide ? MRTX_OCC(false, true) : MRTX_OCC(false, false);
+#undef MRTX_OCC
+    if (e != hipSuccess) return (int)e;
+    if (per_cu < 1) per_cu = 1;
+    int n = per_cu * prop.multiProcessorCount;
+    n = (n + 7) / 8 * 8;
+    *out = n;
+    return 0;
+}
+hipError_t mrtx_launch_paths(const FrameC& f, const PathQ& pq, int S, bool stats, int n_waves, hipStream_t st) {
+    if (pq.n_chunks == 0) return hipSuccess;
+    if (n_waves < 8 || (n_waves & 7) || !pq.counters || pq.n_sub < 1) return hipErrorInvalidValue;
+    const bool wide = f.dem_wide != 0;
+    const dim3 grid((unsigned)n_waves), block(64);
+    if (stats) { if (wide) hipLaunchKernelGGL((mrtx::path_kernel<true, true>), grid, block, 0, st, f, pq);
+                 else hipLaunchKernelGGL((mrtx::path_kernel<true, false>), grid, block, 0, st, f, pq); }
+    else { if (wide) hipLaunchKernelGGL((mrtx::path_kernel<false, true>), grid, block, 0, st, f, pq);
+           else hipLaunchKernelGGL((mrtx::path_kernel<false, false>), grid, block, 0, st, f, pq); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    unsigned rb = (pq.n_chunks + 3u) / 4u;
+    if (rb > 65536u) rb = 65536u;
+    const dim3 rgrid(rb), rblock(256);
+    switch (S) {
+#define MRTX_RES(SV) case SV: hipLaunchKernelGGL((mrtx::resolve_paths_kernel<SV>), rgrid, rblock, 0, st, f, pq); break;
+        MRTX_RES(1) MRTX_RES(2) MRTX_RES(4) MRTX_RES(8) MRTX_RES(16) MRTX_RES(32) MRTX_RES(64)
+#undef MRTX_RES
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 #ifdef MRTX_PROF
 extern "C" __attribute__((visibility("default"))) int mrtx_prof_read(unsigned long long* out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mrtx::g_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
         unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(mrtx::g_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+#ifdef MRTX_PATH_PROF
+extern "C" __attribute__((visibility("default"))) int mrtx_pprof_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mrtx::g_pprof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mrtx::g_pprof), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
 }

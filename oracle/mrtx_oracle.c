@@ -60,7 +60,7 @@ typedef struct OrcScene {
 } OrcScene;
 
 /* indices of the stats array */
-enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_BOUNCE, ST_N };
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_BOUNCE, ST_SUNHIT, ST_N };
 
 /* ------------------------------------------------------------------ spec constants */
 #define PI_D 3.14159265358979323846
@@ -217,6 +217,7 @@ typedef struct Frame {
     float Rf, R2f;
     float Lb[3], rL2, rad2;
     int sun_on; float sc[3], sun_cq, sun_rad;
+    float Sb[3], sun_r2;   /* Sun-disk centre in the moon frame (relative to the Moon centre), radius^2: continuation rays */
     float step, eps, inv_step; int nbis, kmax;
     float polar_rho2, row_hi, col_hi;
     float dlat_scale, dlon_scale;
@@ -277,6 +278,12 @@ static void frame_init(Frame* f, const OrcScene* s) {
     for (i = 0; i < 3; i++) { sr[i] = s->sun_pos[i] - s->eye[i]; f->sc[i] = (float)sr[i]; }
     f->sun_cq = (float)(((sr[0] * sr[0] + sr[1] * sr[1]) + sr[2] * sr[2]) - s->sun_radius * s->sun_radius);
     f->sun_rad = (float)s->sun_radiance;
+    {
+        double sm[3];
+        for (i = 0; i < 3; i++) sm[i] = s->sun_pos[i] - s->center[i];
+        for (i = 0; i < 3; i++) f->Sb[i] = (float)((f->M[i][0] * sm[0] + f->M[i][1] * sm[1]) + f->M[i][2] * sm[2]);
+        f->sun_r2 = (float)(s->sun_radius * s->sun_radius);
+    }
     f->step = s->marching_step;
     f->eps = s->marching_step_eps;
     f->nbis = 0;
@@ -323,6 +330,7 @@ void orc_frame_floats(const OrcScene* s, float* out) {
  * coordinate itself).  Segments that touch the polar cap (rho < 0.2 R) or straddle the +/-180 seam evaluate
  * every step exactly. */
 #define SEG_N 16
+static int orc_force_exact = 0;              /* orc_set_exact(1): every step evaluates (lat, lon) -> (row, col) exactly */
 static uint64_t orc_quad_out_of_range = 0;   /* must stay 0; tests read it through orc_debug_counter() */
 typedef struct Seg { float sa, ra, r1, r2, ca, c1, c2; int exact; } Seg;
 typedef struct Ray { float oa, ob, oc, da, db, dc; } Ray;
@@ -343,7 +351,7 @@ static void seg_setup(const Frame* f, const Ray* r, int ka, float rowA, float co
     exact_rowcol(f, fmaf(sb, r->da, r->oa), fmaf(sb, r->db, r->ob), fmaf(sb, r->dc, r->oc), &rB, &cB, &qB);
     float hw = 0.5f * f->gd.wf;
     float qmin = fminf(q2A, fminf(q2M, qB));
-    sg->exact = (fabsf(cM - colA) > hw) || (fabsf(cB - colA) > hw) || (qmin < f->polar_rho2);
+    sg->exact = orc_force_exact || (fabsf(cM - colA) > hw) || (fabsf(cB - colA) > hw) || (qmin < f->polar_rho2);
     sg->sa = (float)ka * f->step;
     sg->ra = rowA; sg->ca = colA;
     sg->r2 = (fmaf(-2.0f, rM, rowA) + rB) * 0.0078125f;               /* (A - 2M + B) / (N^2/2) */
@@ -712,7 +720,23 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
         Seg bsg;
         int bk = 0;
         if (!march(s, f, &br, 0, 0.0f, &bsg, &bk, st)) {
-            if (s->bg) {   /* the path leaves the Moon: environment radiance along its direction (scene frame) */
+            /* The path leaves the Moon.  The flat Sun-disk sphere IS visible to continuation rays (the reference keeps
+             * the light it bounces onto the Moon small by its radiance 2.0 and by parking it, moon_renderer.py:109-111,
+             * :757-760): distance of the disk centre from the ray, in the moon frame, float32. */
+            if (f->sun_on) {
+                float sa = f->Sb[0] - br.oa, sb = f->Sb[1] - br.ob, sc = f->Sb[2] - br.oc;
+                float bq = fmaf(sc, br.dc, fmaf(sb, br.db, sa * br.da));
+                float pa_ = fmaf(-bq, br.da, sa), pb_ = fmaf(-bq, br.db, sb), pc_ = fmaf(-bq, br.dc, sc);
+                float d2 = fmaf(pc_, pc_, fmaf(pb_, pb_, pa_ * pa_));
+                if (bq > 0.0f && d2 < f->sun_r2) {
+                    o->c[0] = fmaf(thr[0], f->sun_rad, o->c[0]);
+                    o->c[1] = fmaf(thr[1], f->sun_rad, o->c[1]);
+                    o->c[2] = fmaf(thr[2], f->sun_rad, o->c[2]);
+                    st[ST_SUNHIT]++;
+                    break;
+                }
+            }
+            if (s->bg) {   /* environment radiance along its direction (scene frame) */
                 float ex = fmaf(br.dc, f->Mf[2][0], fmaf(br.db, f->Mf[1][0], br.da * f->Mf[0][0]));
                 float ey = fmaf(br.dc, f->Mf[2][1], fmaf(br.db, f->Mf[1][1], br.da * f->Mf[0][1]));
                 float ez = fmaf(br.dc, f->Mf[2][2], fmaf(br.db, f->Mf[1][2], br.da * f->Mf[0][2]));
@@ -830,6 +854,10 @@ float orc_dem_from_ldem(const int16_t* src, int32_t h, int32_t w, int32_t d, flo
         for (c = 0; c < w; c++) dst[(int64_t)r * w + c] /= mx;
     return mx;
 }
+
+/* Test switch: 1 = drop the per-segment quadratic of the texel coordinates and evaluate every march step and bisection
+ * point exactly (what the spec approximates); used to MEASURE the approximation's effect on radiance.  Returns the old value. */
+int orc_set_exact(int on) { int old = orc_force_exact; orc_force_exact = on ? 1 : 0; return old; }
 
 int orc_sizeof_scene(void) { return (int)sizeof(OrcScene); }
 uint64_t orc_debug_counter(void) { return orc_quad_out_of_range; }

@@ -34,7 +34,7 @@ class OrcScene(C.Structure):
 
 
 STAT_NAMES = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches",
-              "background_fetches", "bounce_rays")
+              "background_fetches", "bounce_rays", "bounce_sun_hits")
 
 _lib = None
 
@@ -81,6 +81,8 @@ def lib():
         L.orc_debug_counter.restype = C.c_uint64
         L.orc_set_threads.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_exact.restype = C.c_int
+        L.orc_set_exact.argtypes = [C.c_int]
         assert L.orc_sizeof_scene() == C.sizeof(OrcScene), "OrcScene layout mismatch"
         _lib = L
     return _lib
@@ -89,6 +91,12 @@ def lib():
 def quad_out_of_range():
     """Number of quadratic-segment taps that left [-1, h) x [-1, w) since load; the spec requires 0."""
     return int(lib().orc_debug_counter())
+
+
+def set_exact(on):
+    """Test switch: evaluate the texel coordinates of EVERY march step exactly (no per-segment quadratic).
+    Returns the previous setting."""
+    return bool(lib().orc_set_exact(1 if on else 0))
 
 
 def set_threads(n):

@@ -4,9 +4,9 @@ import numpy as np
 from oracle import orc
 from moonrtx_amd.renderer import MoonRT
 
-EXTRA_KEYS = ("dem_fetches", "mip_fetches", "kernel_ms")
+EXTRA_KEYS = ("dem_fetches", "mip_fetches", "kernel_ms", "primary_ms", "paths_ms")
 STAT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches",
-             "background_fetches", "bounce_rays")
+             "background_fetches", "bounce_rays", "bounce_sun_hits")
 
 
 def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, tile=(32, 32), flags=1, capsules=None):

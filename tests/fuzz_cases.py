@@ -124,10 +124,11 @@ def cases(seed):
             t = rng2.normal(size=3); t /= np.linalg.norm(t)
             s.target = tuple(np.asarray(s.eye) + t * s.radius)
             s.up = tuple(np.cross(t, [0.37, 0.11, 0.92])); s.vfov_deg = float(rng2.uniform(10, 120))
+        extra["inwave"] = bool(rng2.random() < 0.35)   # D6 inside the render wave instead of behind the path queue
         desc = (f"seed {seed} case {case}: dem {dem.shape} frame {s.width}x{s.height} S={s.spp_per_launch} "
                 f"seg=({s.path_seg_min},{s.path_seg_max}) fov {s.vfov_deg:.2f} step {s.marching_step:.2g} flags {flags} tile {tile} "
                 f"blocks {blocks} col {None if col is None else col.shape[:2]} bg {None if bg is None else bg.shape[:2]} "
-                f"caps {0 if capsules is None else len(capsules)} world {extra['world']} parts {extra['parts']}")
+                f"caps {0 if capsules is None else len(capsules)} world {extra['world']} parts {extra['parts']} inwave {extra['inwave']}")
         yield desc, dem, col, bg, s, flags, tile, blocks, extra
         case += 1
 
@@ -172,6 +173,8 @@ def check_case(c):
         flags = int(os.environ["FUZZ_FLAGS"])
     elif not extra.get("count", True):
         flags &= ~_lib.F_COUNT_STATS
+    if extra.get("inwave"):
+        flags |= _lib.F_INWAVE_PATHS
     caps = extra["capsules"]
     lin_o, hits_o, st_o = render_oracle(s, dem, col, bg, blocks=blocks, capsules=caps)
     if extra["world"] > 1:

@@ -1,0 +1,90 @@
+"""D6 (set_uint("path_seg_range", 2, 4), moon_renderer.py:583) through the queue-based path stage:
+render_kernel<MODE 2> hands every primary terrain hit to the persistent path_kernel, resolve_paths_kernel sums the
+samples.  It must equal the in-wave path loop (MRTX_F_INWAVE_PATHS) and the oracle bit for bit -- radiance, hit
+records and every spec counter -- for every wave packing, across accumulation blocks, with overlays, an environment
+map and the Sun disk."""
+import numpy as np
+import pytest
+
+import synth_np
+from common import STAT_KEYS, assert_bit_equal, render_hip, render_oracle
+from moonrtx_amd import _lib
+from moonrtx_amd.scene import named_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rough():
+    return synth_np.corrugated_dem(720, 1440)      # steep relief: continuation rays really do hit terrain again
+
+
+def three_way(scene, dem, color=None, bg=None, blocks=(1,), capsules=None, tile=(32, 32), extra_flags=0):
+    lin_o, hits_o, st_o = render_oracle(scene, dem, color, bg, blocks, capsules=capsules)
+    out = {}
+    for tag, fl in (("queue", 0), ("inwave", _lib.F_INWAVE_PATHS)):
+        for count in (_lib.F_COUNT_STATS, 0):      # counting and production instantiations
+            lin, hits, st, _ = render_hip(scene, dem, color, bg, blocks, capsules=capsules, tile=tile,
+                                          flags=fl | count | extra_flags)
+            assert_bit_equal(lin, lin_o, f"{tag} (count={count}) radiance vs oracle")
+            assert_bit_equal(hits, hits_o, f"{tag} (count={count}) hits vs oracle")
+            if count and len(blocks) == 1:
+                assert {k: st[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}, tag
+            out[(tag, count)] = st
+    assert out[("queue", 1)]["paths_ms"] > 0.0 and out[("inwave", 1)]["paths_ms"] == 0.0
+    return st_o
+
+
+@pytest.mark.parametrize("spp", [1, 2, 4, 8, 16, 32, 64])
+def test_path_queue_every_wave_packing(native_lib, rough, spp):
+    s = named_scene("S1", 70, 50, spp_per_launch=spp)
+    s.path_seg_min, s.path_seg_max = 2, 4
+    st = three_way(s, rough)
+    assert st["bounce_rays"] >= st["primary_hits"] > 0
+
+
+@pytest.mark.parametrize("seg", [(2, 2), (1, 3), (3, 4), (4, 4), (1, 2)])
+def test_path_queue_segment_ranges_with_textures(native_lib, rough, seg):
+    col = synth_np.colour_map(90, 180)
+    bg = np.random.default_rng(11).integers(0, 255, (32, 64, 4), dtype=np.uint8)
+    s = named_scene("S1", 96, 72, spp_per_launch=16)
+    s.path_seg_min, s.path_seg_max = seg
+    st = three_way(s, rough, col, bg)
+    assert st["bounce_rays"] > 0 and st["background_fetches"] > 0
+
+
+def test_path_queue_across_blocks_and_tiles(native_lib, rough):
+    """Accumulation over several launches (the running sum is read back) and a tile size that does not divide the frame."""
+    s = named_scene("S3", 75, 53, spp_per_launch=8)
+    s.path_seg_min, s.path_seg_max = 2, 4
+    three_way(s, rough, blocks=(2, 1, 1), tile=(16, 48))
+    three_way(s, rough, blocks=(3,), extra_flags=_lib.F_NO_CULL | _lib.F_FORCE_WIDE)
+
+
+def test_sun_disk_lights_the_moon_through_continuation_rays(native_lib, rough):
+    """The flat Sun-disk sphere is visible to continuation rays (moon_renderer.py:109-111: "the stray light the disk
+    bounces onto the Moon"; :757-760): a huge disk in front of the night side brightens it, and only through bounces."""
+    s = named_scene("S3", 64, 48, spp_per_launch=16)              # crescent: most of the disc is night
+    s.sun_pos, s.sun_radius, s.sun_radiance = (0.0, -2500.0, 0.0), 1500.0, 2.0     # behind the camera, facing the night side
+    s.path_seg_min, s.path_seg_max = 2, 4
+    st = three_way(s, rough)
+    assert st["bounce_sun_hits"] > 0
+    lit = render_oracle(s, rough)[0]
+    s.path_seg_min, s.path_seg_max = 1, 1
+    dark = render_oracle(s, rough)[0]
+    s.path_seg_min, s.path_seg_max = 2, 4
+    s.sun_radius = 0.01                                           # parked (moon_renderer.py:115)
+    parked, _, stp = render_oracle(s, rough)
+    assert stp["bounce_sun_hits"] == 0
+    night = dark[..., :3].sum(-1) == 0.0
+    assert night.sum() > 200
+    assert lit[..., :3][night].mean() > 20 * max(parked[..., :3][night].mean(), 1e-6)
+
+
+def test_path_queue_with_overlay_tubes(native_lib, rough):
+    from moonrtx_amd import overlays
+    s = named_scene("S1", 120, 90, spp_per_launch=8)
+    s.path_seg_min, s.path_seg_max = 2, 3
+    pos, edges, r, c = overlays.graticule(rotation=s.rotation, tube=0.02)
+    caps = overlays.graph_to_capsules(pos, edges, r, c)
+    three_way(s, rough, capsules=caps)
