@@ -839,6 +839,14 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             HIPCHK(c, hipEventRecord(c->evs[(size_t)b * 3 + 2], c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        {   // path_kernel's watchdog (stats[15]): a wave gave up after 2^24 iterations -- the frame is incomplete
+            unsigned long long wd = 0;
+            HIPCHK(c, hipMemcpy(&wd, c->stats_dev + 15, sizeof wd, hipMemcpyDeviceToHost));
+            if (wd != 0) {
+                HIPCHK(c, hipMemset(c->stats_dev + 15, 0, sizeof wd));
+                return fail(c, MRTX_E_DEVICE, "path_kernel watchdog: %llu wave(s) did not finish their paths", wd);
+            }
+        }
         for (int32_t b = 0; b < n_blocks; b++) {
             float a = 0.0f, p = 0.0f;
             HIPCHK(c, hipEventElapsedTime(&a, c->evs[(size_t)b * 3], c->evs[(size_t)b * 3 + 1]));

@@ -1148,18 +1148,19 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     const uint32_t lane = threadIdx.x;
     // Work distribution.  The records of render block b (b % 8 = a group label: blocks with one label ran on one XCD and
     // cover neighbouring pixels of the same tiles, see the remap in render_kernel) are taken in GROUPS of G consecutive
-    // blocks of one label, handed out by atomic counters in device memory -- one set of counters per XCD of THIS
-    // kernel (HW_REG_XCC_ID), so that at any time the ~640 waves of an XCD march rays that start within about one
+    // blocks of one label, handed out by atomic counters in device memory -- one set of counters per label of THIS
+    // kernel's blocks, so that at any time the ~640 waves of an XCD march rays that start within about one
     // 32x32-pixel tile of each other and share its DEM neighbourhood in that XCD's L2.  (A static deal -- wave w owns
     // chunks w, w + NW, ... -- lets the waves drift apart by dozens of tiles: 46 % L2 hits, 80 GB of HBM reads.)
     // Which wave marches which ray has no influence on any result.
-    const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+    const uint32_t label = blockIdx.x & 7u;   // which blocks share an XCD (observed round-robin dispatch); correctness does not depend on it
     const uint32_t sub = (blockIdx.x >> 3) % (uint32_t)pq.n_sub;
-    uint32_t* const ctr = pq.counters + xcd * (uint32_t)pq.n_sub + sub;
+    uint32_t* const ctr = pq.counters + label * (uint32_t)pq.n_sub + sub;
     const uint32_t npos = (pq.grid_a + 7u) >> 3;                     // render blocks per label
     const uint32_t grp_recs = 64u << (pq.grp_log2 + pq.njobs_log2);   // records in a group
     uint32_t grp_first = 0, grp_used = grp_recs;                      // first block position of the current group; records taken
     bool more = npos > 0;                                             // groups may be left
+    uint32_t iterations = 0;
     uint32_t cnt[ST_N];
     if (STATS) {
 #pragma unroll
@@ -1194,6 +1195,11 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         const uint64_t idle_m = __ballot(state == PS_IDLE);
         const int nidle = __popcll(idle_m);
         const bool can_refill = more;
+        if (nidle == 64 && !can_refill) break;   // every path of this wave is finished and no work is left: the regular exit
+        if (++iterations > (1u << 24)) {         // watchdog: far beyond any real frame (~1e4 iterations); never hang the GPU
+            if (lane == 0) atomicAdd(&f.stats[15], 1ull);
+            break;
+        }
         const int n_seg = __popcll(__ballot(state == PS_NEEDSEG)), n_step = __popcll(__ballot(state == PS_STEP));
         const int n_rare = __popcll(__ballot(state == PS_HITWAIT || state == PS_SHADE));
         bool do_refill, do_seg, do_step, do_rare;
@@ -1234,7 +1240,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 if (state == PS_IDLE) {
                     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
                     const uint32_t vi = grp_used + r;
-                    const uint32_t blk = ((grp_first + (vi >> (6 + pq.njobs_log2))) << 3) + (blockIdx.x & 7u);
+                    const uint32_t blk = ((grp_first + (vi >> (6 + pq.njobs_log2))) << 3) + label;
                     if (vi < grp_recs && blk < pq.grid_a) {
                         const uint32_t chunk = (blk << pq.njobs_log2) + ((vi >> 6) & ((1u << pq.njobs_log2) - 1u));
                         e = chunk * 64u + (vi & 63u);
