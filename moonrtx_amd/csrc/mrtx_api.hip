@@ -54,7 +54,7 @@ struct mrtx_ctx {
     // hand-over records of the deferred path stage (PathQ): 6 float arrays of 64 x chunks + one word per chunk
     float* path_rec = nullptr; uint32_t* path_meta = nullptr; uint64_t path_cap = 0;
     uint32_t* path_ctr = nullptr;        // 8 x 16 work counters of path_kernel
-    int path_nsub = 4, path_grp_log2 = 1;
+    int path_nsub = 4, path_grp_log2 = 1;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
     int path_refill = 8, path_segmin = 24, path_hitmin = 16, path_policy = 0, path_waves_env = 0;
     float* accum = nullptr;

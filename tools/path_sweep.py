@@ -16,6 +16,7 @@ if not os.environ.get("MOONRT_LIB"):
     build.build_native()
 W, H, spp, dem_h, dem_w, col_shape = bench.WORKLOADS[wl]
 S = min(spp, 64)
+dem_h //= int(os.environ.get('DEM_SCALE', '1')); dem_w //= int(os.environ.get('DEM_SCALE', '1'))
 src = synth_ldem(dem_h, dem_w); dem, _ = dem_from_ldem(src, dem_h, dem_w, 1); src.free()
 col = synth_color(*col_shape) if col_shape else None
 scene = named_scene(os.environ.get("SCENE", "S1"), W, H, spp_per_launch=S)
@@ -27,7 +28,7 @@ for (refill, segmin, rare, waves) in settings:
     rt = MoonRT(W, H)
     rt.bind_dem(dem, dem_h, dem_w)
     if col is not None: rt.bind_color(col, *col_shape)
-    rt.apply_scene(scene); rt.set_params(flags=0)
+    rt.apply_scene(scene); rt.set_params(flags=int(os.environ.get("FLAGS", "0")))
     rt.render(1)
     acc = [0.0, 0.0]
     for _ in range(3):
