@@ -32,8 +32,45 @@ def _below(dem, R, p):
     return np.sqrt((p * p).sum(-1)) <= R * _height(dem, p)
 
 
-def render(scene, dem, spp, seed=1234, albedo=None):
-    """Mean linear radiance (H, W, 3) with `spp` jittered samples per pixel, own RNG."""
+def _mix32(x):
+    """lowbias32 on uint32 arrays (the spec's integer hash)."""
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def spec_uniforms(scene, gs, dims=4):
+    """The spec's counter-based uniforms u_d(pixel, sample gs), d < dims, as (dims, H, W) float64 arrays
+    (u_d = (mix32(ks + (d+1)*0x9E3779B9) >> 8) * 2^-24)."""
+    W, H = scene.width, scene.height
+    with np.errstate(over="ignore"):
+        pix = (np.arange(H, dtype=np.uint32)[:, None] * np.uint32(W) + np.arange(W, dtype=np.uint32)[None, :])
+        key0 = _mix32(np.array([np.uint32(scene.seed) ^ np.uint32(0x9E3779B9)], np.uint32))[0]
+        kp = _mix32(pix + key0)
+        ks = _mix32(kp ^ np.uint32((gs * 0x85EBCA6B + 1) & 0xFFFFFFFF))
+        return [(_mix32(ks + np.uint32(((d + 1) * 0x9E3779B9) & 0xFFFFFFFF)) >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+                for d in range(dims)]
+
+
+def _duff_basis(n):
+    """Duff et al., "Building an Orthonormal Basis, Revisited" (the spec's basis about a unit vector)."""
+    sg = np.where(n[:, 2] >= 0, 1.0, -1.0)
+    a = -1.0 / (sg + n[:, 2])
+    b = n[:, 0] * n[:, 1] * a
+    b1 = np.stack([1.0 + sg * n[:, 0] * n[:, 0] * a, sg * b, -sg * n[:, 0]], -1)
+    b2 = np.stack([b, sg + n[:, 1] * n[:, 1] * a, -n[:, 1]], -1)
+    return b1, b2
+
+
+def render(scene, dem, spp, seed=1234, albedo=None, spec_rng=False):
+    """Mean linear radiance (H, W, 3) with `spp` jittered samples per pixel.
+
+    spec_rng=False: own RNG (statistical check).  spec_rng=True: the spec's uniforms for (pixel, sample) and its light-cone
+    parameterisation (Duff basis), still in float64 with library trig and exact evaluation at every step -- the SAME rays up
+    to rounding, so the comparison with the oracle becomes per pixel: only samples that sit on a hit / shadow decision
+    boundary may differ."""
     dem = np.asarray(dem, np.float64)
     W, H, R = scene.width, scene.height, float(scene.radius)
     rng = np.random.default_rng(seed)
@@ -51,8 +88,12 @@ def render(scene, dem, spp, seed=1234, albedo=None):
     step, eps, seps = scene.marching_step, scene.marching_step_eps, scene.scene_epsilon
     out = np.zeros((H, W, 3))
     ys, xs = np.mgrid[0:H, 0:W]
-    for _ in range(spp):
-        fx = xs + rng.random((H, W)); fy = ys + rng.random((H, W))
+    for gs in range(spp):
+        if spec_rng:
+            u0, u1, u2, u3 = spec_uniforms(scene, gs)
+        else:
+            u0, u1, u2, u3 = (rng.random((H, W)) for _ in range(4))
+        fx = xs + u0; fy = ys + u1
         sx = (fx / W * 2 - 1) * th * W / H; sy = (1 - fy / H * 2) * th
         d = wv + sx[..., None] * uv + sy[..., None] * vv
         d /= np.linalg.norm(d, axis=-1, keepdims=True)
@@ -113,11 +154,15 @@ def render(scene, dem, spp, seed=1234, albedo=None):
         tl = Lb - o; dist = np.linalg.norm(tl, axis=-1); ld = tl / dist[:, None]
         sin2 = np.minimum((scene.light_radius / dist) ** 2, 1.0)
         omc = sin2 / (1 + np.sqrt(1 - sin2))
-        ct = 1 - rng.random(len(o)) * omc; st = np.sqrt(np.maximum(0, 1 - ct * ct))
-        ph = 2 * np.pi * rng.random(len(o))
-        hlp = np.where(np.abs(ld[:, [2]]) < 0.9, [[0, 0, 1.0]], [[1.0, 0, 0]])
-        b1 = np.cross(hlp, ld); b1 /= np.linalg.norm(b1, axis=-1, keepdims=True)
-        b2 = np.cross(ld, b1)
+        pix = idx[hh]
+        ct = 1 - u2[pix[:, 0], pix[:, 1]] * omc; st = np.sqrt(np.maximum(0, 1 - ct * ct))
+        ph = 2 * np.pi * u3[pix[:, 0], pix[:, 1]]
+        if spec_rng:
+            b1, b2 = _duff_basis(ld)
+        else:
+            hlp = np.where(np.abs(ld[:, [2]]) < 0.9, [[0, 0, 1.0]], [[1.0, 0, 0]])
+            b1 = np.cross(hlp, ld); b1 /= np.linalg.norm(b1, axis=-1, keepdims=True)
+            b2 = np.cross(ld, b1)
         wi = st[:, None] * (np.cos(ph)[:, None] * b1 + np.sin(ph)[:, None] * b2) + ct[:, None] * ld
         cosi = (nrm * wi).sum(-1)
         lit = cosi > 0
@@ -134,6 +179,5 @@ def render(scene, dem, spp, seed=1234, albedo=None):
                 lit[a[bel]] = False; act[a[bel]] = False
             k += 1
         wgt = np.where(lit, 2 * scene.light_radiance * omc * cosi, 0.0)
-        pix = idx[hh]
         np.add.at(out, (pix[:, 0], pix[:, 1]), wgt[:, None] * alb[None, :])
     return out / spp
