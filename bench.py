@@ -2,10 +2,13 @@
 """bench.py -- headline benchmark of the MoonRTX hot path on MI355X.
 
 Metric (BASELINE.json): Mrays/s + ms/frame at 3840x2160, 64 spp, --downscale-2-sized DEM; 1 ray = 1 primary
-camera sample.  A "step" is one full frame: restart the accumulation cycle
-(`refresh_scene`), render all samples of every pixel, and -- on N > 1 GPUs -- gather the tiles to rank 0.
+camera sample.  A "step" is one full frame of the workload the reference itself runs --
+`path_seg_range (2, 4)` (moon_renderer.py:583): restart the accumulation cycle (`refresh_scene`), render all samples of
+every pixel (camera ray, first vertex + its direct light in render_kernel, everything after the first vertex in
+path_kernel, per-pixel sums in resolve_paths_kernel) and -- on N > 1 GPUs -- gather the tiles to rank 0.
 Inputs (synthetic LOLA-like DEM + colour map) are generated on the device and are
-resident in HBM before the timed region.
+resident in HBM before the timed region.  The direct-light-only frame (path_seg_range (1, 1), round 1's headline) is
+measured beside it and reported under "also".
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -14,6 +17,7 @@ resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,32 +35,46 @@ WORKLOADS = {
     "cfg3": (3840, 2160, 64, 23040, 46080, (13680, 27360)),
     "cfg4": (7680, 4320, 256, 46080, 92160, (13680, 27360)),
 }
+COUNT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "bounce_rays", "height_samples", "colour_fetches",
+              "background_fetches", "dem_fetches", "mip_fetches")
 
 
-def algorithmic_bytes(st, width, height, nominal=False):
+def source_hash():
+    """Identity of the kernel sources a profile was taken with (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    for rel in ("moonrtx_amd/csrc/mrtx_kernels.hip", "moonrtx_amd/csrc/mrtx_api.hip", "moonrtx_amd/csrc/mrtx_device.h",
+                "moonrtx_amd/csrc/Makefile", "include/moonrt.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def algorithmic_bytes(st, width, height, nominal=False, pixels=True):
     """16 B per DEM bilinear evaluation, 16 B per colour fetch, 4 B per background texel,
     32 B per pixel (one float4 radiance + one float4 hit write).
 
-    Strict (default): the DEM evaluations the kernel actually PERFORMS (`dem_fetches`) plus the max-mip texels
-    it reads to prove the others unnecessary (4 B each).  nominal=True: the evaluations the march DEFINES
+    Strict (default): the DEM evaluations the kernels actually PERFORM (`dem_fetches`) plus the max-mip texels
+    they read to prove the others unnecessary (4 B each).  nominal=True: the evaluations the march DEFINES
     (`height_samples`, the oracle's count) -- what a kernel without the result-preserving skip would read."""
     dem = st["height_samples"] if nominal else st["dem_fetches"]
     mip = 0 if nominal else st["mip_fetches"]
-    return 16 * dem + 4 * mip + 16 * st["colour_fetches"] + 4 * st["background_fetches"] + 32 * width * height
+    return (16 * dem + 4 * mip + 16 * st["colour_fetches"] + 4 * st["background_fetches"]
+            + (32 * width * height if pixels else 0))
 
 
 def cpu_baseline(scene, dem_buf, dem_shape, col_buf, col_shape, frame_stats, budget_s=20.0):
     """Time the CPU oracle (kind "port") on a bounded sample of the same workload, on this host's cores.
 
     A short probe crop gives the host's DEM-samples/s; the timed sample is then the largest centred crop of
-    the SAME frame (same scene, DEM, spp) predicted to fit `budget_s` -- the whole frame when it fits.  The
+    the SAME frame (same scene, DEM, spp, path length) predicted to fit `budget_s` -- the whole frame when it fits.  The
     rate is taken in DEM samples per second and converted to whole-frame Mrays/s with the frame's own
     deterministic sample counts, so cheap sky pixels are not mis-priced."""
     import numpy as np
     from oracle import orc
     dem = dem_buf.download(np.float32, dem_shape)
     col = col_buf.download(np.uint8, col_shape + (4,)) if col_buf is not None else None
-    threads = orc.set_threads(min(os.cpu_count() or 1, 16))   # the box's CPU share for one GPU
+    host_cores = os.cpu_count() or 1
+    threads = orc.set_threads(min(host_cores, 16))   # the box's CPU share for one GPU
     W, H = scene.width, scene.height
 
     def crop(frac):
@@ -82,14 +100,41 @@ def cpu_baseline(scene, dem_buf, dem_shape, col_buf, col_shape, frame_stats, bud
     whole = frac >= 1.0
     return {
         "value": round(frame_stats["primary_rays"] / frame_seconds_on_cpu / 1e6, 4), "unit": "Mrays/s",
-        "cores": threads, "kind": "port",
-        "sample": (f"oracle/mrtx_oracle.c, OpenMP x{threads}: " + ("the WHOLE frame" if whole else
+        "cores": threads, "host_cores": host_cores, "kind": "port",
+        "sample": (f"oracle/mrtx_oracle.c, OpenMP x{threads} of {host_cores} host cores: " + ("the WHOLE frame" if whole else
                    f"centred {region[2]-region[0]}x{region[3]-region[1]} crop of the frame")
-                   + f" at {scene.spp_per_launch} spp, same scene/DEM/colour map: {st['primary_rays']} rays, "
-                   f"{st['height_samples']} DEM samples in {dt:.2f} s = {hs_per_s/1e6:.1f} M DEM samples/s"
+                   + f" at {scene.spp_per_launch} spp, path_seg_range ({scene.path_seg_min}, {scene.path_seg_max}), same scene/DEM/colour map: "
+                   f"{st['primary_rays']} rays, {st['height_samples']} DEM samples in {dt:.2f} s = {hs_per_s/1e6:.1f} M DEM samples/s"
                    + ("" if whole else f"; scaled to the frame's {frame_stats['height_samples']} DEM samples")),
         "seconds": round(dt, 2),
     }
+
+
+def facade_rates(dem_buf, dem_h, dem_w, col_buf, col_shape, W, H, cycles=8):
+    """Frames per second THROUGH the PlotOptiX-named surface (moonrtx_amd.tkoptix.TkOptiX.render_cycle: launch(es),
+    on_launch_finished callbacks, the tone-mapped RGBA8 image in host memory) for the two cycles the reference alternates
+    between (moon_renderer.py:121-129): the 1-frame interactive preview and the 64-frame converged image."""
+    from moonrtx_amd.tkoptix import TkOptiX
+    from moonrtx_amd.scene import named_scene
+    out = {}
+    for label, frames in (("preview_1spp", 1), ("converged_64spp", 64)):
+        rt = TkOptiX(width=W, height=H, start_now=False)
+        rt.bind_device_inputs(dem_buf, dem_h, dem_w, col_buf, col_shape)
+        rt.apply_scene_desc(named_scene("S1", W, H, spp_per_launch=min(frames, 64)))
+        rt.set_uint("path_seg_range", 2, 4)
+        rt.set_param(min_accumulation_step=1, max_accumulation_frames=frames)
+        rt.render_cycle()                                   # warm-up (allocations, mip)
+        t = time.perf_counter()
+        for _ in range(cycles):
+            rt.refresh_scene()
+            rt.render_cycle()
+        dt = (time.perf_counter() - t) / cycles
+        out[label] = {"ms_per_cycle": round(dt * 1e3, 3), "cycles_per_s": round(1.0 / dt, 2)}
+        rt.close()
+    out["note"] = ("TkOptiX.render_cycle at %dx%d: launches + callbacks + RGBA8 image read back to host memory; the hit buffer "
+                   "stays on the device until _get_hit_at asks for it. Reference remarks (unnamed RTX GPU, unnamed "
+                   "resolution): ~20 preview steps/s, ~1.5 s per converged image (moon_renderer.py:121-129)" % (W, H))
+    return out
 
 
 def main():
@@ -100,21 +145,22 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--scene", default="S1", choices=["S1", "S2", "S3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the path_seg_range (2,4) side measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements (direct-only frame, facade rates)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--dem-scale", type=int, default=1, help="debug: shrink the DEM by this factor")
-    ap.add_argument("--path-seg", type=int, nargs=2, default=(1, 1), metavar=("MIN", "MAX"),
-                    help="path length in segments; (1,1) = direct light only (headline), the reference sets (2,4)")
+    ap.add_argument("--path-seg", type=int, nargs=2, default=(2, 4), metavar=("MIN", "MAX"),
+                    help="path length in segments; (2,4) is what the reference sets (headline), (1,1) = direct light only")
     ap.add_argument("--inwave-paths", action="store_true", help="A/B: keep D6 paths inside the render wave (MRTX_F_INWAVE_PATHS)")
     args = ap.parse_args()
 
-    import torch
-    from moonrtx_amd import build, dist as mdist
+    from moonrtx_amd import build, _lib
+    build.build_native()
+    _lib.load()
+    from moonrtx_amd import dist as mdist
     from moonrtx_amd.renderer import MoonRT, synth_ldem, synth_color, dem_from_ldem
     from moonrtx_amd.scene import named_scene
-    from moonrtx_amd import _lib
+    import torch
 
-    build.build_native()
     rank, world, local = mdist.init_process_group()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -123,12 +169,14 @@ def main():
     dev = local
     torch.cuda.set_device(dev)
     backend = torch.distributed.get_backend() if world > 1 else None
+    dist_world = torch.distributed.get_world_size() if world > 1 else 1
 
     W, H, spp, dem_h, dem_w, col_shape = WORKLOADS[args.workload]
     dem_h //= args.dem_scale
     dem_w //= args.dem_scale
     S = min(spp, 64)
     n_blocks = spp // S
+    seg = tuple(args.path_seg)
 
     # ---- inputs, resident in HBM before anything is timed
     t0 = time.perf_counter()
@@ -140,13 +188,14 @@ def main():
 
     scene = named_scene(args.scene, W, H, spp_per_launch=S)
     scene.max_spp = spp
-    scene.path_seg_min, scene.path_seg_max = args.path_seg
+    scene.path_seg_min, scene.path_seg_max = seg
     rt = MoonRT(W, H, device=dev, rank=rank, world=world)
     rt.bind_dem(dem_buf, dem_h, dem_w)
     if col_buf is not None:
         rt.bind_color(col_buf, col_shape[0], col_shape[1])
     rt.apply_scene(scene)
     gather = mdist.FrameGather(rt, torch.device("cuda", dev))
+    base_flags = _lib.F_INWAVE_PATHS if args.inwave_paths else 0
 
     def step():
         rt.reset()
@@ -157,66 +206,134 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def timed(n):
+        acc = {"kernel_ms": 0.0, "primary_ms": 0.0, "paths_ms": 0.0}
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            st_ = step()
+            for k in acc:
+                acc[k] += st_[k]
+        barrier()
+        el = time.perf_counter() - t
+        return el, {k: v / max(1, n) for k, v in acc.items()}
+
     # one counted frame (deterministic sample counts for the roofline), untimed
-    base_flags = _lib.F_INWAVE_PATHS if args.inwave_paths else 0
     rt.set_params(flags=_lib.F_COUNT_STATS | base_flags)
     counted = step()
     rt.set_params(flags=base_flags)
     for _ in range(args.warmup):
         step()
-
-    barrier()
-    t = time.perf_counter()
-    kernel_ms = primary_ms = paths_ms = 0.0
-    for _ in range(args.steps):
-        st_ = step()
-        kernel_ms += st_["kernel_ms"]; primary_ms += st_["primary_ms"]; paths_ms += st_["paths_ms"]
-    barrier()
-    elapsed = time.perf_counter() - t
-    kernel_ms /= max(1, args.steps); primary_ms /= max(1, args.steps); paths_ms /= max(1, args.steps)
+    elapsed, km = timed(args.steps)
 
     # whole-job numbers: max time over ranks, counts summed over ranks
     red_dev = "cpu" if backend == "gloo" else "cuda"
-    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
-    keys = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches", "background_fetches",
-            "dem_fetches", "mip_fetches")
-    cnt = torch.tensor([counted[k] for k in keys], dtype=torch.int64, device=red_dev)
+    mine = torch.tensor([elapsed, km["kernel_ms"], km["primary_ms"], km["paths_ms"]], dtype=torch.float64, device=red_dev)
+    tt = mine.clone()
+    cnt = torch.tensor([counted[k] for k in COUNT_KEYS], dtype=torch.int64, device=red_dev)
+    per_rank = None
     if world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [[round(float(v), 4) for v in t_] for t_ in allr]
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.SUM)
-    elapsed, kernel_ms = float(tt[0]), float(tt[1])
-    frame = dict(zip(keys, (int(v) for v in cnt)))
+    elapsed, kernel_ms, primary_ms, paths_ms = (float(v) for v in tt)
+    frame = dict(zip(COUNT_KEYS, (int(v) for v in cnt)))
 
-    # Beside the headline (direct light): the same frame with the reference's own default
-    # path_seg_range (2, 4) (moon_renderer.py:583), a few untimed-region steps on one GPU, reported as a secondary figure.
-    also = None
-    if world == 1 and tuple(args.path_seg) == (1, 1) and not args.no_secondary:
-        scene.path_seg_min, scene.path_seg_max = 2, 4
+    # Beside the headline: the direct-light-only frame (path_seg_range (1, 1)).  Its counters are also what
+    # render_kernel<MODE 2> performs inside the headline frame (same camera rays, vertices and shadow rays).
+    also, direct_counts = None, None
+    if world == 1 and seg[1] > 1 and not args.no_secondary:
+        scene.path_seg_min, scene.path_seg_max = 1, 1
+        rt.apply_scene(scene)
+        rt.set_params(flags=_lib.F_COUNT_STATS)
+        direct_counts = step()
+        rt.set_params(flags=0)
+        step()
+        e2, k2 = timed(3)
+        also = {"path_seg_range": [1, 1], "value": round(W * H * spp / (e2 / 3) / 1e6, 2), "unit": "Mrays/s",
+                "ms_per_step": round(e2 / 3 * 1e3, 3), "kernel_ms": round(k2["kernel_ms"], 3),
+                "roofline_frac_strict": round(algorithmic_bytes(direct_counts, W, H) / (k2["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "direct light only (round 1's headline): one launch of render_kernel<64, false, wide, 0, false>; the reference never runs this"}
+        scene.path_seg_min, scene.path_seg_max = seg
         rt.apply_scene(scene)
         rt.set_params(flags=base_flags)
-        step()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        k2 = sum(step()["kernel_ms"] for _ in range(3)) / 3.0
-        torch.cuda.synchronize()
-        e2 = (time.perf_counter() - t2) / 3.0
-        also = {"path_seg_range": [2, 4], "value": round(W * H * spp / e2 / 1e6, 2), "unit": "Mrays/s",
-                "ms_per_step": round(e2 * 1e3, 3), "kernel_ms": round(k2, 3),
-                "note": "the reference's default path length (D6: up to 3 further segments with next-event estimation)"}
-        scene.path_seg_min, scene.path_seg_max = args.path_seg
-        rt.apply_scene(scene)
+
+    facade = None
+    if rank == 0 and world == 1 and args.workload == "cfg3" and not args.no_secondary:
+        try:
+            facade = facade_rates(dem_buf, dem_h, dem_w, col_buf, col_shape, W, H)
+        except Exception as e:     # a side figure must not take the headline down
+            facade = {"error": repr(e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rays = W * H * spp
-        # roofline of the dominant (render) kernel: this rank's algorithmic bytes / its launch duration
+        wide = "true" if (dem_h + 4) * (dem_w + 4) * 8 > 0xFFFFFFFF else "false"
+        queue = seg[1] > 1 and not args.inwave_paths
+        # ---- roofline.  Bytes are ALGORITHMIC; time is the HIP-event duration of the kernels.
         px_adj = -32 * W * H + 32 * W * H // world
-        ach = (algorithmic_bytes(counted, W, H) + px_adj) / (kernel_ms * 1e-3) / 1e9
-        ach_nom = (algorithmic_bytes(counted, W, H, nominal=True) + px_adj) / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        frame_bytes = algorithmic_bytes(counted, W, H) + px_adj
+        frame_bytes_nom = algorithmic_bytes(counted, W, H, nominal=True) + px_adj
+        kernels = {}
+        if queue and direct_counts is not None:
+            a_bytes = algorithmic_bytes(direct_counts, W, H)
+            kernels["render_kernel<%d, false, %s, 2, false>" % (S, wide)] = {
+                "ms": round(primary_ms, 3), "algorithmic_bytes": int(a_bytes),
+                "achieved": round(a_bytes / (primary_ms * 1e-3) / 1e9, 1), "frac": round(a_bytes / (primary_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "does": "camera ray, march, first vertex, light sample + shadow march, continuation ray set-up, hand-over records"}
+            p_bytes = frame_bytes - a_bytes
+            kernels["path_kernel<false, %s> + resolve_paths_kernel<%d>" % (wide, S)] = {
+                "ms": round(paths_ms, 3), "algorithmic_bytes": int(p_bytes),
+                "achieved": round(p_bytes / (paths_ms * 1e-3) / 1e9, 1), "frac": round(p_bytes / (paths_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "does": "continuation-ray marches, later vertices and their shadow rays (persistent waves fed from the record queue), per-pixel sums"}
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["ms"])
+            dom_bytes, dom_ms = kernels[dom]["algorithmic_bytes"], kernels[dom]["ms"]
+        else:
+            mode = 1 if seg[1] > 1 else 0
+            dom = "render_kernel<%d, false, %s, %d, false>" % (S, wide, mode)
+            dom_bytes, dom_ms = frame_bytes, kernel_ms
+        ach = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # PMC evidence comes from SEPARATE rocprofv3 passes of this same command (tools/profile_bench.sh): accepted only
+        # if it was taken with these very kernel sources
+        prof, prof_note = None, "no profile file"
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if world == 1 and args.workload == "cfg3" and os.path.isfile(tpath):
-            traffic = json.load(open(tpath))   # from the rocprofv3 --pmc passes of this same command (tools/profile_bench.sh)
+            cand = json.load(open(tpath))
+            if cand.get("source_hash") == source_hash() and cand.get("path_seg") == list(seg):
+                prof, prof_note = cand, f"profiles/{cand['tag']}_summary.md (separate --pmc passes of this command, kernel sources {cand['source_hash']})"
+            else:
+                prof_note = (f"profiles/traffic_latest.json is stale (taken with kernel sources {cand.get('source_hash')}, "
+                             f"path_seg {cand.get('path_seg')}; these are {source_hash()}, {list(seg)})")
+        pk = None
+        if prof:
+            for name, v in prof["kernels"].items():
+                if name.split("<")[0] == dom.split("<")[0]:
+                    pk = v
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None if pk is None else int(pk["hbm_bytes"]),
+                "kernel": dom, "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": int(dom_bytes),
+                "limiter": "VALU issue + dependent-load latency (not HBM bandwidth): see valu_issue_frac / hbm_utilisation",
+                "valu_issue_frac": None if pk is None else pk.get("valu_issue_frac"),
+                "hbm_utilisation": None if pk is None else round(pk["hbm_bytes"] / (pk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "lanes_per_valu_inst": None if pk is None else pk.get("lanes_per_valu"),
+                "l2_hit": None if pk is None else pk.get("l2_hit"),
+                "profile": prof_note,
+                "profile_kernel_ms": None if pk is None else pk["avg_ms"],
+                "frame": {"kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(frame_bytes),
+                          "achieved": round(frame_bytes / (kernel_ms * 1e-3) / 1e9, 1),
+                          "frac": round(frame_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "achieved_nominal": round(frame_bytes_nom / (kernel_ms * 1e-3) / 1e9, 1),
+                          "frac_nominal": round(frame_bytes_nom / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "kernels": kernels or None,
+                "note": "achieved = ALGORITHMIC bytes / HIP-event duration: 16 B per DEM evaluation PERFORMED + 4 B per max-mip "
+                        "texel + 16 B per colour fetch + 4 B per background texel + 32 B per pixel (SURVEY.md 8(d)); it is a "
+                        "cache-served throughput, NOT an HBM utilisation (that is hbm_utilisation, from the PMC traffic); "
+                        "*_nominal counts every evaluation the march defines (the max-mip skip proves most unnecessary, results "
+                        "unchanged) and can exceed 1"}
         out = {
             "metric": "Mrays/s (primary camera samples) at 3840x2160, 64 spp, downscale-2 DEM" if args.workload == "cfg3"
                       else f"Mrays/s (primary camera samples), {args.workload}",
@@ -226,33 +343,28 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {W}x{H}, {spp} spp, DEM {dem_h}x{dem_w} f32"
                                    + (f", colour {col_shape[0]}x{col_shape[1]} RGBA8" if col_shape else ", grey albedo")
-                                   + f", scene {args.scene}",
+                                   + f", scene {args.scene}, path_seg_range {seg}"
+                                   + (" = the reference's setting (moon_renderer.py:583)" if seg == (2, 4) else ""),
                        "parallelism": f"image tiles 32x32 dealt round-robin (2-D lattice) over {world} GPU(s), active tiles gathered to rank 0"
                                       + (", RCCL gather of float4 radiance+hits to rank 0" if world > 1 else ""),
                        "march": "step 5e-3, eps 3e-4, scene_epsilon 1e-4, 1 light sample + shadow ray per path vertex, "
-                                f"path_seg_range {tuple(args.path_seg)}" + (" (direct light only)" if args.path_seg[1] <= 1 else "")},
+                                f"path_seg_range {seg}" + (" (direct light only)" if seg[1] <= 1 else
+                                                          (", paths continued inside the render wave" if args.inwave_paths else
+                                                           ", paths continued by persistent waves behind a record queue"))},
+            "distributed": {"backend": backend, "world_size": dist_world,
+                            "per_rank_[wall_s, kernel_ms, primary_ms, paths_ms]": per_rank,
+                            "gather_bytes_per_rank": getattr(gather, "last_bytes", None)},
             "kernel_ms": round(kernel_ms, 3), "primary_ms": round(primary_ms, 3), "paths_ms": round(paths_ms, 3),
             "frame_counts": frame,
             "bytes_per_ray": round(algorithmic_bytes(frame, W, H) / rays, 2),
             "bytes_per_ray_nominal": round(algorithmic_bytes(frame, W, H, nominal=True) / rays, 2),
-            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": None if traffic is None else round(traffic["hbm_bytes_per_launch"]),
-                         "traffic_source": None if traffic is None else f"profiles/{traffic['tag']}_summary.md: FETCH_SIZE x {traffic['fetch_factor']} (calibrated on a known 8-byte-per-lane stream) + WRITE_SIZE",
-                         "algorithmic_bytes": int(algorithmic_bytes(counted, W, H) + px_adj),
-                         "kernel": "mrtx::render_kernel<%d, false, %s, %s, false>" % (
-                             S, "true" if (dem_h + 4) * (dem_w + 4) * 8 > 0xFFFFFFFF else "false",
-                             "true" if args.path_seg[1] > 1 else "false"),
-                         "achieved_nominal": round(ach_nom, 1), "frac_nominal": round(ach_nom / HBM_PEAK_GBS, 4),
-                         "note": "achieved = algorithmic bytes / HIP-event launch duration, bytes = 16 B per DEM "
-                                 "evaluation PERFORMED + 4 B per max-mip texel + 16 B per colour fetch + 4 B per "
-                                 "background texel + 32 B per pixel; *_nominal counts every evaluation the march "
-                                 "defines (the max-mip skip proves most of them unnecessary, results unchanged); "
-                                 f"strict frac vs the 6290 GB/s measured-copy peak: {round(ach / 6290.0, 4)}"},
+            "roofline": roof,
             "inputs_s": round(t_inputs, 2),
         }
         if also is not None:
             out["also"] = also
+        if facade is not None:
+            out["facade"] = facade
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, dem_buf, (dem_h, dem_w), col_buf, col_shape, frame,
                                                args.cpu_budget_s)

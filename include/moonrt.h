@@ -177,6 +177,9 @@ int mrtx_render_part(mrtx_ctx* ctx, int32_t n_blocks, int32_t part, int32_t n_pa
 int mrtx_read_linear(mrtx_ctx* ctx, float* rgba_out);
 int mrtx_read_rgba8(mrtx_ctx* ctx, uint8_t* out);
 int mrtx_read_hits(mrtx_ctx* ctx, float* xyzd_out);
+/* One texel of the hit buffer (16 bytes over PCIe): what rt._get_hit_at(x, y) needs per mouse event
+ * (moon_renderer.py:1137-1142) without pulling the 133 MB buffer of a 4K frame after every launch. */
+int mrtx_read_hit(mrtx_ctx* ctx, int32_t x, int32_t y, float xyzd_out[4]);
 int mrtx_samples_done(mrtx_ctx* ctx, uint32_t* out);
 
 /* ---- multi-GPU exchange step (new: the reference is single-GPU) -------------------------------

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mrtx_read_linear": (C.c_int, [_VP, _VP]),
     "mrtx_read_rgba8": (C.c_int, [_VP, _VP]),
     "mrtx_read_hits": (C.c_int, [_VP, _VP]),
+    "mrtx_read_hit": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "mrtx_samples_done": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
     "mrtx_shard_bytes": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64)]),
     "mrtx_shard_bytes_active": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
@@ -92,10 +93,57 @@ SIGNATURES = {
 }
 
 _lib = None
+_preloaded_runtime = None
 
 
 class NativeLibraryError(RuntimeError):
     pass
+
+
+def hip_runtimes_loaded():
+    """Paths of every libamdhip64 copy mapped into this process (more than one means two HIP/HSA runtimes are alive:
+    the second one to initialise finds no GPUs)."""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if "libamdhip64" in os.path.basename(path):
+                    real = os.path.realpath(path)
+                    if real not in seen:
+                        seen.append(real)
+    except OSError:
+        pass
+    return seen
+
+
+def _preload_torch_hip_runtime():
+    """ONE HIP runtime per process, whatever the import order.
+
+    libmoonrt.so needs `libamdhip64.so.7` (a SONAME); the torch wheel bundles its own copy of the runtime and asks for it by
+    FILE name (`libamdhip64.so`, RPATH $ORIGIN).  The dynamic loader reuses an already-loaded library when the requested name
+    equals its SONAME or its file -- so "torch first" gives one runtime (torch's copy satisfies libmoonrt's SONAME request),
+    but "libmoonrt first" used to give two (/opt/rocm's for libmoonrt, then torch's for torch), and torch / RCCL then
+    reported "no GPUs found".  When a torch installation is present its copy is therefore loaded here, BEFORE
+    libmoonrt.so and without importing torch: either order now ends on that single copy.  Without torch the system
+    runtime is used.  MOONRT_HIP_RUNTIME=system skips this (then import torch before this package)."""
+    global _preloaded_runtime
+    if os.environ.get("MOONRT_HIP_RUNTIME") == "system" or hip_runtimes_loaded():
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.isfile(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            _preloaded_runtime = path
+        except OSError:
+            pass            # fall back to the system runtime; load() checks for duplicates below
 
 
 def load():
@@ -107,6 +155,7 @@ def load():
         raise NativeLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C moonrtx_amd/csrc` (needs hipcc). There is no CPU fallback.")
+    _preload_torch_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
@@ -120,8 +169,21 @@ def load():
         fn.argtypes = args
     if lib.mrtx_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"ABI version mismatch: library {lib.mrtx_abi_version()}, host {ABI_VERSION}")
+    rts = hip_runtimes_loaded()
+    if len(rts) > 1:
+        raise NativeLibraryError("two HIP runtimes are loaded in this process (" + ", ".join(rts) + "): the second one to "
+                                 "initialise will see no GPUs. Import moonrtx_amd (or torch) before anything else loads "
+                                 "another libamdhip64, or set LD_LIBRARY_PATH so that both resolve to one copy.")
     _lib = lib
     return lib
+
+
+def assert_single_hip_runtime():
+    """Called before a torch.distributed / RCCL group is created: fail loudly instead of 'no GPUs found'."""
+    rts = hip_runtimes_loaded()
+    if len(rts) > 1:
+        raise NativeLibraryError("two HIP runtimes are loaded in this process: " + ", ".join(rts))
+    return rts
 
 
 def vec3(v):

@@ -908,6 +908,15 @@ int mrtx_read_hits(mrtx_ctx* c, float* out) {
     return MRTX_OK;
 }
 
+int mrtx_read_hit(mrtx_ctx* c, int32_t x, int32_t y, float out[4]) {
+    if (!c || !out) return MRTX_E_INVALID;
+    if (x < 0 || y < 0 || x >= c->cfg.width || y >= c->cfg.height) return fail(c, MRTX_E_INVALID, "pixel (%d, %d) outside the frame", x, y);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemcpyAsync(out, c->hits + 4 * ((size_t)y * (size_t)c->cfg.width + (size_t)x), 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MRTX_OK;
+}
+
 // The layout both ends of the gather use for the scene as it stands: active tiles only while the sky cull is in force
 // (no environment map, no overlay geometry, culling not disabled), the full layout otherwise.  Every rank derives
 // every rank's list from its own copy of the scene -- identical on all ranks by contract -- so nothing is negotiated.

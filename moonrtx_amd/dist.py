@@ -49,8 +49,11 @@ def init_process_group(backend=None):
 
     MOONRT_DIST_BACKEND=gloo + MOONRT_ONE_DEVICE=1 rehearse the multi-rank path on a single-GPU box (every rank
     renders on device 0, the gather is staged through host memory); production is one rank per GPU over RCCL."""
+    from . import _lib
+    _lib.load()                      # settles which HIP runtime this process uses (one copy, see _lib._preload_torch_hip_runtime)
     import torch
     import torch.distributed as dist
+    _lib.assert_single_hip_runtime()
     rank, world, local = env_rank_world()
     if os.environ.get("MOONRT_ONE_DEVICE") == "1":
         local = 0

@@ -210,10 +210,20 @@ class MoonRT:
         self._check(self._lib.mrtx_read_linear(self._ctx, out.ctypes.data), "mrtx_read_linear")
         return out
 
-    def read_rgba8(self):
-        out = np.empty((self.height, self.width, 4), np.uint8)
+    def read_rgba8(self, out=None):
+        """The tone-mapped frame; `out` (a C-contiguous (H, W, 4) uint8 array) is reused when given."""
+        if out is None:
+            out = np.empty((self.height, self.width, 4), np.uint8)
+        elif out.shape != (self.height, self.width, 4) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (height, width, 4) uint8 array")
         self._check(self._lib.mrtx_read_rgba8(self._ctx, out.ctypes.data), "mrtx_read_rgba8")
         return out
+
+    def read_hit(self, x, y):
+        """One texel of the hit buffer: (hx, hy, hz, hd), hd <= 0 == miss."""
+        out = (C.c_float * 4)()
+        self._check(self._lib.mrtx_read_hit(self._ctx, int(x), int(y), out), "mrtx_read_hit")
+        return float(out[0]), float(out[1]), float(out[2]), float(out[3])
 
     def read_hits(self):
         out = np.empty((self.height, self.width, 4), np.float32)

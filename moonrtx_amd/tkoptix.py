@@ -9,7 +9,9 @@ method) is provided with the same name, argument meaning and threading contract:
     (moon_renderer.py:574, renderer_status.py:239), after the last launch of a cycle it calls the
     `set_accum_done_cb` callback WITH the padlock held (renderer_video.py:260, :276-281), then idles
     until `refresh_scene()` (moon_renderer.py:867-871);
-  * `_get_hit_at(x, y)` reads the host copy of the hit buffer, no GPU call (moon_renderer.py:1138).
+  * `_get_hit_at(x, y)` fetches ONE texel of the hit buffer from the device (16 bytes, under the padlock): the buffer
+    itself stays in HBM -- reading all of it back after every launch costs 10.9 ms at 4K against a 0.9 ms preview launch
+    (moon_renderer.py:1138 calls it once per mouse event).
 
 What differs, by design: there is no Tk window here (no Tk on a headless GPU node) -- `_root`/`_canvas`
 are None and the `_gui_*` handler slots are plain attributes a viewer may call.  One launch adds
@@ -23,6 +25,50 @@ import warnings
 import numpy as np
 
 __version__ = "0.19.2"   # the PlotOptiX API level this facade mirrors (main.py:185-201)
+
+
+def write_tiff16(path, rgb16):
+    """Uncompressed little-endian baseline TIFF, 3 x 16 bits per pixel, one strip."""
+    import struct
+    a = np.ascontiguousarray(rgb16, "<u2")
+    h, w, ch = a.shape
+    if ch != 3:
+        raise ValueError("write_tiff16 takes an (h, w, 3) uint16 array")
+    data = a.tobytes()
+    n_tags = 10
+    ifd_off = 8
+    bps_off = ifd_off + 2 + n_tags * 12 + 4
+    data_off = bps_off + 6
+    tags = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 3, bps_off), (259, 3, 1, 1), (262, 3, 1, 2), (273, 4, 1, data_off),
+            (277, 3, 1, 3), (278, 4, 1, h), (279, 4, 1, len(data)), (284, 3, 1, 1)]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<2sHI", b"II", 42, ifd_off))
+        f.write(struct.pack("<H", n_tags))
+        for tag, typ, cnt, val in tags:
+            f.write(struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<HH", val, 0) if typ == 3 and cnt == 1 else struct.pack("<I", val)))
+        f.write(struct.pack("<I", 0))
+        f.write(struct.pack("<HHH", 16, 16, 16))
+        f.write(data)
+
+
+def write_png16(path, rgb16):
+    """PNG, colour type 2 (RGB), bit depth 16."""
+    import struct, zlib
+    a = np.ascontiguousarray(rgb16, ">u2")
+    h, w, ch = a.shape
+    if ch != 3:
+        raise ValueError("write_png16 takes an (h, w, 3) uint16 array")
+    raw = np.zeros((h, 1 + w * 6), np.uint8)
+    raw[:, 1:] = a.view(np.uint8).reshape(h, w * 6)          # filter type 0 on every scanline
+
+    def chunk(kind, payload):
+        return struct.pack(">I", len(payload)) + kind + payload + struct.pack(">I", zlib.crc32(kind + payload) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)))
+        f.write(chunk(b"IDAT", zlib.compress(raw.tobytes(), 6)))
+        f.write(chunk(b"IEND", b""))
 
 
 def _as3(v):
@@ -92,8 +138,7 @@ class TkOptiX:
         self._moon_name = None
         self._sun_name = None
         self._frames_done = 0
-        self._image = np.zeros((self._height, self._width, 4), np.uint8)
-        self._hits = np.zeros((self._height, self._width, 4), np.float32)
+        self._image = np.zeros((self._height, self._width, 4), np.uint8)   # reused for every read-back
         self._warned = set()
         if start_now:
             self.start()
@@ -195,7 +240,7 @@ class TkOptiX:
         if "Overlay" in self._postproc and tex is not None and tex.shape[:2] == (self._height, self._width):
             self._rt.upload_overlay(tex)
             if self._frames_done:
-                self._image = self._rt.read_rgba8()
+                self._read_image()
 
     def _bind_moon_material(self):
         moon = self._geoms.get(self._moon_name) if self._moon_name else None
@@ -385,9 +430,16 @@ class TkOptiX:
             self._push_params(spp)
         self._rt.render(1)
         self._frames_done += 1
-        self._image = self._rt.read_rgba8()
-        self._hits = self._rt.read_hits()
+        self._read_image()              # 33 MB at 4K, 0.7 ms; the hit buffer stays on the device (see _get_hit_at)
         return self._frames_done >= launches
+
+    def _read_image(self):
+        try:
+            got = self._rt.read_rgba8(out=self._image)
+        except TypeError:                # a backend without the `out` parameter
+            got = self._rt.read_rgba8()
+        if got is not None:
+            self._image = got
 
     def _render_loop(self):
         while True:
@@ -458,7 +510,13 @@ class TkOptiX:
     def _get_hit_at(self, x, y):
         """-> (hx, hy, hz, hd), hd <= 0 == miss (moon_renderer.py:1138-1142, renderer_navigation.py:195-203)."""
         if 0 <= x < self._width and 0 <= y < self._height:
-            h = self._hits[int(y), int(x)]
+            with self._padlock:
+                if self._rt is None or not self._frames_done:
+                    return 0.0, 0.0, 0.0, -1.0
+                if hasattr(self._rt, "read_hit"):
+                    h = self._rt.read_hit(int(x), int(y))
+                else:
+                    h = self._rt.read_hits()[int(y), int(x)]
             return float(h[0]), float(h[1]), float(h[2]), float(h[3])
         return 0.0, 0.0, 0.0, -1.0
 
@@ -466,7 +524,10 @@ class TkOptiX:
         return self._image
 
     def save_image(self, file_name, bps="Bps8"):
-        """save_image(path, bps="Bps8"|"Bps16") -- renderer_dialogs.py:1222-1224."""
+        """save_image(path, bps="Bps8"|"Bps16") -- renderer_dialogs.py:1222-1224 (".tiff" is saved with 16 bits per sample).
+
+        Bps16 writes 16 bits or raises -- it never degrades to 8 bits silently: uncompressed baseline TIFF (.tif/.tiff) or
+        PNG (.png), both written here (Pillow cannot write 16-bit RGB)."""
         from PIL import Image
         bps = getattr(bps, "name", bps)
         with self._padlock:
@@ -476,15 +537,36 @@ class TkOptiX:
                 e = float(self._floats.get("tonemap_exposure", 0.9))
                 img = np.clip(np.power(np.maximum(e * lin, 0.0), g), 0.0, 1.0)
                 arr = np.floor(img * 65535.0 + 0.5).astype(np.uint16)
-                try:
-                    import imageio.v3 as iio
-                    iio.imwrite(file_name, arr)
-                    return
-                except Exception:
-                    arr8 = (arr >> 8).astype(np.uint8)
-                    Image.fromarray(arr8).save(file_name)
-                    return
+                ext = str(file_name).lower().rsplit(".", 1)[-1]
+                if ext in ("tif", "tiff"):
+                    write_tiff16(file_name, arr)
+                elif ext == "png":
+                    write_png16(file_name, arr)
+                else:
+                    raise ValueError(f"16 bits per sample need a .tiff/.tif or .png file name, not {file_name!r}")
+                return
             Image.fromarray(self._image[..., :3]).save(file_name)
+
+    # ------------------------------------------------------------------ headless conveniences (bench.py, tools/)
+    def bind_device_inputs(self, dem_buf, dem_h, dem_w, col_buf=None, col_shape=None):
+        """Device-resident DEM / colour map (moonrtx_amd.renderer.DeviceBuffer) instead of set_displacement / set_texture_2d."""
+        with self._padlock:
+            self._rt.bind_dem(dem_buf, dem_h, dem_w)
+            if col_buf is not None:
+                self._rt.bind_color(col_buf, col_shape[0], col_shape[1])
+            self._dirty = True
+
+    def apply_scene_desc(self, s):
+        """Everything init_renderer + update_view push for a moonrtx_amd.scene.SceneDesc, through the PlotOptiX-named calls."""
+        self.set_float("scene_epsilon", s.scene_epsilon); self.set_float("marching_step", s.marching_step)
+        self.set_float("marching_step_eps", s.marching_step_eps)
+        self.set_float("tonemap_exposure", s.exposure); self.set_float("tonemap_gamma", s.gamma)
+        self.set_uint("path_seg_range", s.path_seg_min, s.path_seg_max)
+        self.set_data("moon", geom="ParticleSetTextured", geom_attr="DisplacedSurface", pos=list(s.center), u=list(s.u),
+                      v=list(s.v), r=s.radius)
+        self.setup_camera("cam1", cam_type="Pinhole", eye=list(s.eye), target=list(s.target), up=list(s.up), fov=s.vfov_deg)
+        self.setup_light("sun", pos=list(s.light_pos), color=s.light_radiance, radius=s.light_radius, in_geometry=False)
+        self.set_data("sun_disk", geom="ParticleSet", mat="flat", pos=[list(s.sun_pos)], r=s.sun_radius, c=s.sun_radiance)
 
     # ------------------------------------------------------------------ encoder (NVENC in the reference)
     def encoder_create(self, *a, **k):

@@ -30,6 +30,8 @@ class RecordingBackend:
                 return np.full((self.height, self.width, 4), min(255, self.blocks), np.uint8)
             if name == "read_hits":
                 h = np.zeros((self.height, self.width, 4), np.float32); h[2, 3] = (1, 2, 3, 290.5); return h
+            if name == "read_hit":
+                return (1.0, 2.0, 3.0, 290.5) if tuple(a[:2]) == (3, 2) else (0.0, 0.0, 0.0, 0.0)
             if name == "read_linear":
                 return np.zeros((self.height, self.width, 4), np.float32)
             if name == "close":
@@ -126,6 +128,8 @@ def test_update_view_sequence_and_cycle_restart():
     rt._optix.set_camera_fov(2.0)
     assert be.last("set_camera")[1][3] == 2.0
     assert rt._get_hit_at(3, 2) == (1.0, 2.0, 3.0, 290.5) and rt._get_hit_at(99, 99)[3] <= 0
+    # the hit buffer is never pulled back wholesale: one texel per query (moon_renderer.py:1138 asks once per mouse event)
+    assert not [c for c in be.calls if c[0] == "read_hits"] and be.last("read_hit")[1] == (3, 2)
     rt.close()
 
 
@@ -227,4 +231,34 @@ def test_reference_grid_graphs_become_capsules():
     assert caps.shape == (3900, 12) and np.allclose(np.linalg.norm(caps[3267:, 0:3], axis=1), np.linalg.norm(g["labels_pos"][g["labels_edges"][:, 0]], axis=1), atol=1e-4)
     rt.update_graph("grid_lines", r=0.0); rt.update_graph("grid_labels", r=0.0)      # show_moon_grid(False)
     assert len(be.last("set_capsules")[1][0]) == 0
+    rt.close()
+
+
+def test_save_image_16_bits_is_really_16_bits(tmp_path):
+    """renderer_dialogs.py:1222-1224: ".tiff" is saved with bps="Bps16" -- 16 bits per sample on disk, never a silent 8."""
+    import struct
+    from PIL import Image
+    be = RecordingBackend(16, 8)
+    lin = np.zeros((8, 16, 4), np.float32)
+    lin[..., 0] = np.linspace(0.0, 1.0, 16)[None, :]; lin[..., 1] = 0.25; lin[..., 2] = 1.0e-3
+    be.read_linear = lambda: lin
+    rt = TkOptiX(width=16, height=8, backend=be)
+    rt.set_float("tonemap_exposure", 0.9); rt.set_float("tonemap_gamma", 2.2)
+    want = np.floor(np.clip((0.9 * lin[..., :3]) ** (1 / 2.2), 0, 1) * 65535.0 + 0.5).astype(np.uint16)
+    p = tmp_path / "frame.tiff"
+    rt.save_image(str(p), bps="Bps16")
+    raw = p.read_bytes()
+    assert raw[:4] == b"II*\x00"
+    (n_tags,) = struct.unpack_from("<H", raw, 8)
+    tags = {struct.unpack_from("<H", raw, 10 + 12 * i)[0]: struct.unpack_from("<HHII", raw, 10 + 12 * i) for i in range(n_tags)}
+    assert tags[256][3] == 16 and tags[257][3] == 8 and tags[277][3] & 0xFFFF == 3
+    assert struct.unpack_from("<HHH", raw, tags[258][3]) == (16, 16, 16)
+    got = np.frombuffer(raw, "<u2", count=8 * 16 * 3, offset=tags[273][3]).reshape(8, 16, 3)
+    assert np.array_equal(got, want) and len(np.unique(got[..., 0])) == 16          # 16 distinct levels: not 8-bit data
+    assert Image.open(str(p)).size == (16, 8)
+    q = tmp_path / "frame.png"
+    rt.save_image(str(q), bps="Bps16")
+    assert q.read_bytes()[24] == 16                                                  # IHDR bit depth
+    with pytest.raises(ValueError):
+        rt.save_image(str(tmp_path / "frame.jpg"), bps="Bps16")
     rt.close()

@@ -410,6 +410,42 @@ def test_rccl_async_gather_of_views():
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+def test_one_hip_runtime_whatever_the_import_order(native_lib, dem_small):
+    """libmoonrt.so FIRST (this test session loaded it long ago), then torch + an RCCL group, in ONE process: the loader
+    preloads the torch wheel's own libamdhip64 before libmoonrt.so, so both sides share a single HIP/HSA runtime --
+    with two copies the later one sees no GPUs ("ProcessGroupNCCL is only supported with GPUs, no GPUs found")."""
+    import os
+    from moonrtx_amd import _lib, dist as mdist
+    from moonrtx_amd.renderer import MoonRT
+    s = named_scene("S1", 96, 64, spp_per_launch=8)
+    rt = MoonRT(s.width, s.height)                      # the HIP runtime is initialised through libmoonrt.so here
+    rt.upload_dem(dem_small); rt.apply_scene(s)
+    rt.render(1)
+    ref = rt.read_linear()
+    import torch
+    import torch.distributed as dist
+    assert len(_lib.assert_single_hip_runtime()) == 1
+    assert torch.cuda.is_available() and torch.cuda.device_count() >= 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        g = mdist.FrameGather(rt, torch.device("cuda", 0))
+        rt.reset()
+        st = g.render_and_gather(1)                     # world 1: render + (no-op) gather through the same entry point
+        assert st["primary_rays"] == s.width * s.height * 8
+        assert_bit_equal(rt.read_linear(), ref, "frame after the RCCL group came up in the same process")
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)                              # RCCL really talks to the device
+        assert float(t.sum()) == 4.0
+    finally:
+        if created:
+            dist.destroy_process_group()
+        rt.close()
+
+
 def test_rgba8_tonemap_within_one_lsb(native_lib, dem_small):
     s = named_scene("S2", 64, 64, spp_per_launch=4)
     lin, _, _, rgba = render_hip(s, dem_small)

@@ -1,12 +1,22 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for bench.py on the GPU box.  Usage: tools/profile_bench.sh <tag>
-# kernel-trace/stats and each PMC group run as SEPARATE passes (never combined).
+# Collect the rocprofv3 evidence for bench.py on the GPU box.  Usage: tools/profile_bench.sh <tag> [extra bench args]
+# kernel-trace/stats and each PMC group run as SEPARATE passes (never combined).  Then, on the build machine:
+#   python tools/summarise_profile.py gpurun_out/prof_<tag> <tag>    (writes profiles/<tag>_*, profiles/traffic_latest.json)
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary $*"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py $ARGS"
+python3 - <<PY > $OUT/meta.json
+import json, sys
+args = "$ARGS".split()
+seg = [2, 4]
+if "--path-seg" in args:
+    i = args.index("--path-seg"); seg = [int(args[i + 1]), int(args[i + 2])]
+json.dump({"command": "python3 bench.py $ARGS", "path_seg": seg}, sys.stdout)
+PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1 || exit 1
