@@ -416,7 +416,7 @@ void mrtx_default_params(MrtxParams* p) {
     p->spp_per_launch = 64; p->max_spp = 64;   // :130
     p->seed = 1;
     p->const_albedo[0] = p->const_albedo[1] = p->const_albedo[2] = 75.0f / 255.0f;  // lut[128], gamma 2.2
-    p->flags = MRTX_F_COUNT_STATS;
+    p->flags = 0;   // production kernels; MRTX_F_COUNT_STATS selects the counting instantiations (2-3x slower)
 }
 
 int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {

@@ -983,7 +983,10 @@ __device__ __forceinline__ float tree_sum(float v) {
 // cap they spill ~200 registers, and in an experiment at a 72-VGPR cap one such instantiation (<64, STATS, !WIDE, BOUNCE,
 // OVERLAY>) miscomputed a sample with no undefined behaviour the compiler could name.  They only render the counted
 // frame, so they get the registers they ask for.
-#define MRTX_BOUNCE_WAVES(STATS) ((STATS) ? 2 : MRTX_MIN_WAVES_BOUNCE)
+#ifndef MRTX_BOUNCE_STATS_WAVES
+#define MRTX_BOUNCE_STATS_WAVES 2   // tools/spill_repro.py builds with 7 to bring the spilled configuration back
+#endif
+#define MRTX_BOUNCE_WAVES(STATS) ((STATS) ? MRTX_BOUNCE_STATS_WAVES : MRTX_MIN_WAVES_BOUNCE)
 template <int S, bool STATS, bool WIDE, int MODE, bool OVERLAY>
 __global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MODE == 1 ? MRTX_BOUNCE_WAVES(STATS) : MRTX_MIN_WAVES)
 render_kernel(const FrameC f, const PathQ pq) {

@@ -76,6 +76,9 @@ class MoonRT:
         self.params = MrtxParams()
         self._lib.mrtx_default_params(C.byref(self.params))
         self._keepalive = {}
+        import os
+        if os.environ.get("MOONRT_DEFAULT_FLAGS"):      # test / debugging aid: e.g. 1 = maintain the sample counters
+            self.set_params(flags=int(os.environ["MOONRT_DEFAULT_FLAGS"]))
 
     # ---- plumbing
     def _check(self, rc, what):

@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# contexts created by the tests keep the deterministic sample counters unless a test asks otherwise (the library's own
+# default is the production kernels, flags = 0)
+os.environ.setdefault("MOONRT_DEFAULT_FLAGS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
