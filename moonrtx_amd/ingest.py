@@ -240,7 +240,9 @@ def _open_rgb(filepath, downscale=1):
         a = read_image(filepath)                      # uncompressed TIFF: zero-copy
         if a.dtype != np.uint8:
             a = (a >> (8 * (a.dtype.itemsize - 1))).astype(np.uint8)
-        if downscale > 1 and a.ndim == 3:
+        if a.ndim == 2:                                # greyscale map: three equal channels, like cv2.imread gives the reference
+            a = np.repeat(a[..., None], 3, axis=2)
+        if downscale > 1:
             h, w = a.shape[0] // downscale, a.shape[1] // downscale
             a = a[:h * downscale, :w * downscale].reshape(h, downscale, w, downscale, -1).mean((1, 3)).astype(np.uint8)
         return a
@@ -285,10 +287,43 @@ def load_starmap(filepath, target_width):
             pass
     from PIL import Image
     Image.MAX_IMAGE_PIXELS = None
-    im = Image.open(filepath).convert("RGB")
-    if target_width < im.width:
-        im = im.resize((target_width, int(im.height * target_width / im.width)), Image.BICUBIC)
-    star = np.asarray(im, np.float32) * np.float32(1 / 255)
-    np.clip(star, 0, 1, out=star)
+    star = np.asarray(Image.open(filepath).convert("RGB"), np.float32)
+    star *= np.float32(1 / 255)
+    if target_width < star.shape[1]:
+        star = resize_cubic(star, int(star.shape[0] * target_width / star.shape[1]), target_width)
+        np.clip(star, 0, 1, out=star)
     _save_cache(cache_base, star, fingerprint)
     return star
+
+
+def _cubic_taps(n_dst, n_src):
+    """Source indices (n_dst, 4) and weights (n_dst, 4) of cv2.resize(..., interpolation=cv2.INTER_CUBIC): pixel-centre
+    alignment x_src = (x_dst + 0.5) * n_src / n_dst - 0.5, Keys kernel with a = -0.75, replicated border, no pre-filter."""
+    a = np.float32(-0.75)
+    x = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
+    x0 = np.floor(x)
+    t = (x - x0).astype(np.float32)
+    w = np.empty((n_dst, 4), np.float32)
+    w[:, 0] = ((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a
+    w[:, 1] = ((a + 2) * t - (a + 3)) * t * t + 1
+    w[:, 2] = ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1
+    w[:, 3] = 1 - w[:, 0] - w[:, 1] - w[:, 2]
+    idx = np.clip(x0.astype(np.int64)[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+    return idx, w
+
+
+def resize_cubic(img, out_h, out_w):
+    """float32 (h, w, c) -> (out_h, out_w, c), the rule data_loader.py:415-416 applies through cv2.resize
+    (INTER_CUBIC on float32 data): separable, columns first, in bands to bound the temporaries."""
+    src = np.asarray(img, np.float32)
+    ci, cw = _cubic_taps(out_w, src.shape[1])
+    ri, rw = _cubic_taps(out_h, src.shape[0])
+    out = np.empty((out_h, out_w) + src.shape[2:], np.float32)
+    for y0 in range(0, out_h, 256):
+        y1 = min(out_h, y0 + 256)
+        rows = np.unique(ri[y0:y1])
+        band = src[rows]                                             # the source rows this band needs
+        hb = sum(band[:, ci[:, k]] * cw[:, k].reshape((1, -1) + (1,) * (src.ndim - 2)) for k in range(4))
+        pos = np.searchsorted(rows, ri[y0:y1])
+        out[y0:y1] = sum(hb[pos[:, k]] * rw[y0:y1, k].reshape((-1, 1) + (1,) * (src.ndim - 2)) for k in range(4))
+    return out

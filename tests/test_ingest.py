@@ -134,3 +134,62 @@ def test_load_elevation_data_on_device_matches_oracle(native_lib, tmp_path, d):
         assert meta["downscale"] == d and meta["version"] == 1 and abs(meta["radius_scale"] - scale) < 1e-9
         again, scale2 = ingest.load_elevation_data(p, d)
         assert np.array_equal(again, got) and scale2 == scale
+
+
+def test_load_starmap_resize_rule_clip_and_cache(tmp_path):
+    """data_loader.py:371-425: BGR->RGB, /255, cubic resize (cv2.INTER_CUBIC: pixel-centre alignment, Keys kernel a = -0.75,
+    no pre-filter) only when the source is wider than the target, clip to [0, 1], `.w<N>.npy` + `.json` cache."""
+    from PIL import Image
+    from moonrtx_amd import ingest
+    h, w = 24, 48
+    ramp = np.tile(np.linspace(20, 220, w).round().astype(np.uint8)[None, :, None], (h, 1, 3))
+    ramp[:, :, 1] = 128                                       # a constant channel
+    ramp[:, 30:, 2] = 255; ramp[:, :30, 2] = 0               # a step: cubic overshoot must be clipped
+    p = tmp_path / "stars.tif"
+    Image.fromarray(ramp).save(p)
+    same = ingest.load_starmap(str(p), 96)                    # target wider than the source: no resize
+    assert same.shape == (h, w, 3) and same.dtype == np.float32
+    assert np.array_equal(same, ramp.astype(np.float32) * np.float32(1 / 255))
+    half = ingest.load_starmap(str(p), 24)
+    assert half.shape == (int(h * 24 / w), 24, 3) and half.dtype == np.float32
+    assert np.allclose(half[..., 1], 128 / 255, atol=1e-6)                            # constants survive
+    want = (np.arange(24) + 0.5) * 2 - 0.5                                            # source x of every output column
+    lin = (20 + want * (200 / (w - 1))) / 255
+    assert np.abs(half[5, 2:-2, 0] - lin[2:-2]).max() < 2.5e-3                        # cubic convolution reproduces a ramp
+    assert half.min() >= 0.0 and half.max() <= 1.0 and half[5, 14, 2] < half[5, 15, 2]  # clipped, step kept
+    # the rule itself, against the 4-tap formula evaluated by hand at one output pixel (row 3, column 10, channel 0)
+    src = ramp.astype(np.float32) * np.float32(1 / 255)
+    def taps(xd, n_dst, n_src):
+        x = (xd + 0.5) * n_src / n_dst - 0.5; x0 = int(np.floor(x)); t = x - x0; a = -0.75
+        wts = [((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a, ((a + 2) * t - (a + 3)) * t * t + 1,
+               ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1]
+        wts.append(1 - sum(wts))
+        return [min(max(x0 - 1 + k, 0), n_src - 1) for k in range(4)], wts
+    ci, cw = taps(10, 24, w); ri, rw = taps(3, 12, h)
+    by_hand = sum(rw[a] * sum(cw[b] * src[ri[a], ci[b], 0] for b in range(4)) for a in range(4))
+    assert abs(by_hand - half[3, 10, 0]) < 1e-6
+    # cache round trip: the second call must not touch the source
+    assert (tmp_path / "stars.tif.w24.npy").is_file() and (tmp_path / "stars.tif.w24.json").is_file()
+    p.write_bytes(p.read_bytes())                             # same bytes, new mtime: fingerprint changes -> recomputed
+    again = ingest.load_starmap(str(p), 24)
+    assert np.array_equal(again, half)
+    assert ingest.load_starmap(str(tmp_path / "missing.tif"), 24) is None
+
+
+def test_greyscale_colour_map_with_downscale_and_cache(tmp_path):
+    """A 2-D (greyscale) colour map: block-mean downscale applies, the cache holds three equal channels (no east-west
+    mirroring), and the cached load equals the fresh one."""
+    from PIL import Image
+    from moonrtx_amd import ingest
+    g = (np.arange(16 * 32).reshape(16, 32) % 251).astype(np.uint8)
+    p = tmp_path / "grey.tif"
+    Image.fromarray(g).save(p)
+    a = ingest.load_color_data(str(p), gamma=2.2, downscale=2)
+    assert a.shape == (8, 16, 4) and (a[..., 3] == 255).all()
+    assert np.array_equal(a[..., 0], a[..., 1]) and np.array_equal(a[..., 1], a[..., 2])
+    mean = g.reshape(8, 2, 16, 2).mean((1, 3)).astype(np.uint8)
+    assert np.array_equal(a[..., 0], ingest.albedo_lut(2.2)[mean])          # block mean, then the LUT; not mirrored
+    cached = np.load(str(p) + ".ds2.npy")
+    assert cached.shape == (8, 16, 3)
+    b = ingest.load_color_data(str(p), gamma=2.2, downscale=2)
+    assert np.array_equal(a, b)
