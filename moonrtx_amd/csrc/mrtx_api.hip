@@ -42,6 +42,8 @@ hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipSt
 hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, int shift, hipStream_t st);
 hipError_t mrtx_launch_color_pairs(const uint32_t* src, void* dst, int h, int w, hipStream_t st);
 hipError_t mrtx_launch_mip_pairs(const float* mip, float* out_pairs, int rows, int pitch, hipStream_t st);
+hipError_t mrtx_launch_hmip(const float* mip, int mh, int mw, int shift, float* out, int hh, int hw, int hshift, int h, int w,
+                            hipStream_t st);
 hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out, hipStream_t st);
 
 struct mrtx_ctx {
@@ -61,6 +63,7 @@ struct mrtx_ctx {
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
     float* dem = nullptr; int dem_h = 0, dem_w = 0;   // padded (h+4) x (w+4) copy, always owned
+    float* hmip = nullptr; int hm_h = 0, hm_w = 0, hm_shift = 0;       // horizon mip: cells of 8 max-mip cells, dilated by one cell (see horizon_kend)
     float* mip = nullptr; int mip_h = 0, mip_w = 0, mip_shift = 0;   // max-mip of it, cell 2^mip_shift texels (+ one-cell border)
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
@@ -226,6 +229,10 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     k.path_seg_min = c->prm.path_seg_min; k.path_seg_max = c->prm.path_seg_max < 1 ? 1 : c->prm.path_seg_max;
     for (int i = 0; i < 3; i++) k.const_albedo[i] = c->prm.const_albedo[i];
     f.dem = c->dem; k.color = c->color; k.bg = c->bg;
+    k.hmip = (c->prm.flags & MRTX_F_NO_SKIP) ? nullptr : c->hmip; k.hm_h = c->hm_h; k.hm_w = c->hm_w; k.hm_shift = c->hm_shift;
+    k.hm_cell = (float)(1 << c->hm_shift);
+    k.hm_krow = (float)((double)c->dem_h / kPiD);
+    k.hm_kcol = (float)(1.05 * (double)c->dem_w / (2.0 * kPiD));
     f.mip = c->mip; f.mip_pitch = c->mip_w + 2; f.mip_h = c->mip_h; f.mip_w = c->mip_w; f.mip_shift = c->mip_shift;
     f.dem_pitch = c->dem_w + 4;
 #if MRTX_DEM_PAIRS
@@ -487,6 +494,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
+    if (c->hmip) (void)hipFree(c->hmip);
     if (c->color) (void)hipFree(c->color);
     if (c->bg) (void)hipFree(c->bg);
     if (c->overlay) (void)hipFree(c->overlay);
@@ -507,6 +515,8 @@ static int ingest_dem(mrtx_ctx* c, const float* dev_src, int32_t h, int32_t w) {
     HIPCHK(c, mrtx_launch_pad_dem(dev_src, c->dem, h, w, c->stream));
     if (c->mip) { HIPCHK(c, hipFree(c->mip)); }
     c->mip = nullptr; c->mip_shift = 0;   // (re)built by mrtx_render for the march step in force
+    if (c->hmip) { HIPCHK(c, hipFree(c->hmip)); }
+    c->hmip = nullptr;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dem_h = h; c->dem_w = w;
     return MRTX_OK;
@@ -521,6 +531,8 @@ static int ensure_mip(mrtx_ctx* c) {
     if (c->mip && c->mip_shift == shift) return MRTX_OK;
     if (c->mip) { HIPCHK(c, hipFree(c->mip)); }
     c->mip = nullptr;
+    if (c->hmip) { HIPCHK(c, hipFree(c->hmip)); }
+    c->hmip = nullptr;
     const int cell = 1 << shift;
     c->mip_h = (c->dem_h + cell - 1) / cell; c->mip_w = (c->dem_w + cell - 1) / cell;
     const size_t cells = (size_t)(c->mip_h + 2) * (c->mip_w + 2);
@@ -529,6 +541,10 @@ static int ensure_mip(mrtx_ctx* c) {
     hipError_t e = hipMalloc((void**)&c->mip, (cells + 1) * 2 * sizeof(float));   // row pairs + one element of slack for the 16-byte load
     if (e == hipSuccess) e = mrtx_launch_mip(c->dem, c->dem_h, c->dem_w, plain, c->mip_h, c->mip_w, shift, c->stream);
     if (e == hipSuccess) e = mrtx_launch_mip_pairs(plain, c->mip, c->mip_h + 2, c->mip_w + 2, c->stream);
+    c->hm_shift = shift + 3;
+    c->hm_h = (c->dem_h + (cell << 3) - 1) / (cell << 3); c->hm_w = (c->dem_w + (cell << 3) - 1) / (cell << 3);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->hmip, (size_t)c->hm_h * c->hm_w * sizeof(float));
+    if (e == hipSuccess) e = mrtx_launch_hmip(plain, c->mip_h, c->mip_w, shift, c->hmip, c->hm_h, c->hm_w, c->hm_shift, c->dem_h, c->dem_w, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(plain);
     HIPCHK(c, e);
@@ -725,7 +741,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     f.n_blocks = (uint32_t)n_blocks;
     const bool stats = (c->prm.flags & MRTX_F_COUNT_STATS) != 0;
     if (c->prm.flags & MRTX_F_FORCE_WIDE) f.dem_wide = 1;
-    if (c->prm.flags & MRTX_F_NO_SKIP) f.mip = nullptr;
+    if (c->prm.flags & MRTX_F_NO_SKIP) f.mip = nullptr;   // (build_frame leaves the horizon mip out as well)
     uint64_t culled_px = 0;
     if (c->tile_dirty.size() != (size_t)c->n_local) c->tile_dirty.assign((size_t)c->n_local, 0);
     const bool overlay = !c->caps_host.empty();

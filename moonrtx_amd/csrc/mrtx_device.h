@@ -72,6 +72,11 @@ struct FrameCold {
     const int32_t* caps_off;   // n_local_tiles + 1
     const int32_t* caps_idx;
     int32_t n_caps;
+    // horizon mip (horizon_kend in mrtx_kernels.hip): hm_h x hm_w cells of 2^hm_shift texels, or null
+    const float* hmip;
+    int32_t hm_h, hm_w, hm_shift;
+    float hm_cell;                  // cell size in texels
+    float hm_krow, hm_kcol;         // angle -> texel rows (h / pi); angle -> texel columns (1.05 w / 2 pi)
 };
 
 struct FrameC {

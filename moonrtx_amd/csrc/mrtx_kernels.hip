@@ -385,14 +385,65 @@ struct MarchState {
     RayQ rq;
     float rowA, colA, q2A;
     int ka;
+    int kend;   // no step beyond this one can be at/below the surface (horizon_kend); kmax when nothing is known
 };
+
+// RESULT-PRESERVING end of a shadow / continuation march: once an ASCENDING ray (b = o.d >= 0, so r^2(s) grows
+// monotonically) is above everything its remaining ground track can reach, no later step can be at/below the surface,
+// and the march can stop there instead of stepping -- or setting up empty segments -- until it leaves the bounding sphere.
+// "Everything it can reach" comes from the HORIZON MIP: cells of Cc = 8 fine-mip cells (512 texels at cfg 3), each holding
+// the maximum of D over the cell DILATED by Cc texels on every side (rows clamp, columns wrap), so one look-up at the
+// ray's origin bounds D over any ground track that stays within Cc texels of it.  The track's extent is bounded from the
+// chord to the sphere exit L: it subtends phi <= 1.03 L / r0 at the centre (the ray stays above its origin radius r0), at most
+// phi * h/pi rows and asin(sin phi / cos(lat_max)) * w/2pi <= 1.05 phi / (cos(lat0) - phi) * w/2pi columns; the test needs
+// both (+4 texels for taps and the quadratic's bulge) inside Cc, otherwise nothing is cut.  Then the last step that can
+// matter is where r^2(s) reaches (R Dc)^2 (1 + 1e-5).  Approximate v_sqrt / v_rcp are fine: every bound is padded.
+// Radiance, hits and the spec counters are unchanged (MRTX_F_NO_SKIP switches this off together with the max-mip).
+__device__ __forceinline__ int horizon_kend(const FrameC& f, const MarchState& m) {
+    int kend = f.kmax;
+    const float* hm = CF(f)->hmip;
+    if (hm != nullptr && m.rq.b >= 0.0f) {
+        const float a = m.rq.a, b = m.rq.b, q0 = m.rq.q0;
+        const float c = f.R2f - q0;                        // >= 0: the origin is inside the bounding sphere
+        const float L = c * __builtin_amdgcn_rcpf(b + __builtin_amdgcn_sqrtf(fmaf(a, c, b * b)) + 1.0e-30f) * 1.02f;
+        const float inv_cos = __builtin_amdgcn_sqrtf(q0 * __builtin_amdgcn_rcpf(fmaxf(m.q2A, 1.0e-30f)));   // r0 / rho0
+        const float phi = L * __builtin_amdgcn_rsqf(q0) * 1.03f;   // 2 asin(L / 2 r0) <= 1.003 L / r0 for L <= r0 / 4; r(s) >= r0
+        const float den = 1.0f - phi * inv_cos;            // cos(lat0) - phi, in units of cos(lat0)
+        const float drow = fmaf(phi, CF(f)->hm_krow, 4.0f);
+        const float dcol = fmaf(phi * CF(f)->hm_kcol, inv_cos * __builtin_amdgcn_rcpf(fmaxf(den, 0.25f)), 4.0f);
+        const float cell = CF(f)->hm_cell;
+        if ((c >= 0.0f) & (phi <= 0.25f) & (den >= 0.5f) & (drow <= cell) & (dcol <= cell)) {
+            int i = (int)floorf(m.rowA) >> CF(f)->hm_shift, j = (int)floorf(m.colA) >> CF(f)->hm_shift;
+            i = max(0, min(i, CF(f)->hm_h - 1)); j = max(0, min(j, CF(f)->hm_w - 1));
+            const float rd = f.Rf * hm[i * CF(f)->hm_w + j];
+            const float d = (rd * rd) * 1.00001f - q0;
+            if (d <= 0.0f) kend = 0;
+            else {
+                const float sc = d * __builtin_amdgcn_rcpf(b + __builtin_amdgcn_sqrtf(fmaf(a, d, b * b))) * 1.001f;
+                kend = min(f.kmax, (int)(sc * f.inv_step) + 2);
+            }
+        }
+    }
+    return kend;
+}
+// STATS builds: the steps the spec evaluates after a march was cut at kend (every step while the ray is inside)
+__device__ __forceinline__ uint32_t steps_after(const FrameC& f, const MarchState& m, int k_from) {
+    uint32_t n = 0;
+    for (int k = k_from; k <= f.kmax; k++) {
+        const float sk = (float)k * f.step;
+        const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
+        if (!(fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f)) break;
+        n++;
+    }
+    return n;
+}
 
 // Start of a march: exact coordinates at the origin, r^2(s) coefficients; returns `go` (false: the march is over before
 // its first step).
 // ... with the exact texel coordinates of the origin already known (m.rowA, m.colA)
-template <bool PRIMARY>
+template <bool PRIMARY, bool STATS>
 __device__ __forceinline__ bool march_begin_at(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
-                                               MarchState& m) {
+                                               MarchState& m, uint32_t* cnt) {
     m.oa = oa; m.ob = ob; m.oc = oc; m.da = da; m.db = db; m.dc = dc;
     m.q2A = fmaf(ob, ob, oa * oa);
     m.rq.q0 = fmaf(oc, oc, m.q2A);
@@ -407,15 +458,22 @@ __device__ __forceinline__ bool march_begin_at(const FrameC& f, float oa, float 
         const float s1 = f.step;
         const float pa = fmaf(s1, da, oa), pb = fmaf(s1, db, ob), pc = fmaf(s1, dc, oc);
         go = fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f;
+        m.kend = horizon_kend(f, m);
+        if (go && m.kend < 1) {          // already above everything in reach: no step can hit
+            if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, 1);
+            go = false;
+        }
+    } else {
+        m.kend = f.kmax;
     }
     return go;
 }
-template <bool PRIMARY>
+template <bool PRIMARY, bool STATS>
 __device__ __forceinline__ bool march_begin(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
-                                            MarchState& m) {
+                                            MarchState& m, uint32_t* cnt) {
     float q2;
     exact_rowcol(f, oa, ob, oc, m.rowA, m.colA, q2);
-    return march_begin_at<PRIMARY>(f, oa, ob, oc, da, db, dc, m);
+    return march_begin_at<PRIMARY, STATS>(f, oa, ob, oc, da, db, dc, m, cnt);
 }
 
 // ONE 16-step segment of a march (the lanes that call it are still marching): anchors + skip interval, the steps
@@ -429,6 +487,7 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
     float rowB, colB, q2B;
     PROF_BEGIN(6);
     seg_setup<STATS>(f, oa, ob, oc, da, db, dc, m.rq, ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
+    if (!PRIMARY) sg.jhi = max(min(sg.jhi, m.kend - ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
     PROF_END(6);
     PROF_BEGIN(7);
     if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, 1, sg.jlo - 1);
@@ -452,6 +511,10 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
         const float sk = (float)k * f.step;
         const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
         go = (PRIMARY ? (sk <= smax) : (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f)) & (k < f.kmax);
+        if (!PRIMARY && go && k >= m.kend) {           // cut by the horizon bound: the rest of the ray is above the terrain
+            if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, k + 1);
+            go = false;
+        }
     }
     m.ka = ka + SEG_N; m.rowA = rowB; m.colA = colB; m.q2A = q2B;
 }
@@ -465,7 +528,7 @@ __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float
                                       float smax, Seg& sg, float& sk_hit, uint32_t* cnt) {
     MarchState m;
     bool hit = false;
-    bool go = march_begin<PRIMARY>(f, oa, ob, oc, da, db, dc, m);
+    bool go = march_begin<PRIMARY, STATS>(f, oa, ob, oc, da, db, dc, m, cnt);
     while (go) march_segment<WIDE, PRIMARY, STATS, BATCH>(f, m, smax, sg, go, hit, sk_hit, cnt);
     return hit;
 }
@@ -1186,7 +1249,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     float sk_hit = 0.0f;
     Vertex v;
     float t0r = 1.0f, t1r = 1.0f, t2r = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, carried = 0.0f, wgt = 0.0f;
-    m.oa = m.ob = m.oc = m.da = m.db = m.dc = 0.0f; m.rq.q0 = m.rq.b = m.rq.a = 0.0f; m.rowA = m.colA = m.q2A = 0.0f; m.ka = 0;
+    m.oa = m.ob = m.oc = m.da = m.db = m.dc = 0.0f; m.rq.q0 = m.rq.b = m.rq.a = 0.0f; m.rowA = m.colA = m.q2A = 0.0f; m.ka = 0; m.kend = 0;
     sg.sa = sg.ra = sg.r1 = sg.r2 = sg.ca = sg.c1 = sg.c2 = 0.0f; sg.jlo = 1; sg.jhi = 0; sg.exact = false;
     v.pa = v.pb = v.pc = v.na = v.nb = v.nc = v.al0 = v.al1 = v.al2 = 0.0f;
 
@@ -1253,7 +1316,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                         const float4 r0 = pq.ray0[e], r1 = pq.ray1[e], r2 = pq.ray2[e];
                         if ((mt & 0x80000000u) && r0.x < 0.5f * MRTX_NO_PATH) {
                             m.rowA = r2.y; m.colA = r2.z;
-                            const bool go = march_begin_at<false>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m);
+                            const bool go = march_begin_at<false, STATS>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
                             t0r = r1.z; t1r = r1.w; t2r = r2.x;
                             ks = __float_as_uint(r2.w);
                             hit = false; shadow = false; have_c = false;
@@ -1272,6 +1335,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 seg_setup<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, m.rq, m.ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
                 if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, 1, sg.jlo - 1);
                 m.rowA = rowB; m.colA = colB; m.q2A = q2B;   // the next segment starts where this one ends
+                sg.jhi = max(min(sg.jhi, m.kend - m.ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
                 j = sg.jlo;
                 if (j <= sg.jhi) state = PS_STEP; else segend = true;
             }
@@ -1299,7 +1363,11 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             const int k = m.ka + SEG_N;
             const float sk = (float)k * f.step;
             const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
-            const bool go = (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f) & (k < f.kmax);
+            bool go = (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f) & (k < f.kmax);
+            if (go && k >= m.kend) {                         // cut by the horizon bound (see horizon_kend)
+                if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, k + 1);
+                go = false;
+            }
             m.ka = k;
             state = go ? PS_NEEDSEG : PS_ENDED;
         }
@@ -1340,7 +1408,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 float soa, sob, soc, swa, swb, swc;
                 if (light_sample(f, v, ul1, ul2, soa, sob, soc, swa, swb, swc, carried)) {
                     if (STATS) cnt[ST_SHADOW]++;
-                    const bool go = march_begin<false>(f, soa, sob, soc, swa, swb, swc, m);
+                    const bool go = march_begin<false, STATS>(f, soa, sob, soc, swa, swb, swc, m, cnt);
                     hit = false; shadow = true;
                     state = go ? PS_NEEDSEG : PS_ENDED;
                 } else {
@@ -1355,7 +1423,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 float boa, bob, boc, bda, bdb, bdc;
                 if (continue_path(f, v, ks, seg, t0r, t1r, t2r, boa, bob, boc, bda, bdb, bdc)) {
                     if (STATS) cnt[ST_BOUNCE]++;
-                    const bool go = march_begin<false>(f, boa, bob, boc, bda, bdb, bdc, m);
+                    const bool go = march_begin<false, STATS>(f, boa, bob, boc, bda, bdb, bdc, m, cnt);
                     hit = false; shadow = false;
                     state = go ? PS_NEEDSEG : PS_ENDED;
                 } else {
@@ -1716,6 +1784,33 @@ __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, in
     }
 }
 
+// Horizon mip (horizon_kend): cell (i, j) of Cc = C << 3 texels holds the maximum of D over texel rows [Cc i - Cc, Cc i + 2 Cc)
+// (clamped) x columns [Cc j - Cc, Cc j + 2 Cc) (wrapped), taken from the plain max-mip of C-texel cells (whose cells are
+// themselves dilated by the two-texel tap border).  (hh) x (hw) floats, a few thousand cells.
+__global__ void hmip_build_kernel(const float* __restrict__ mip, int mh, int mw, int shift, float* __restrict__ out,
+                                  int hh, int hw, int hshift, int h, int w) {
+    const int mp = mw + 2, Cc = 1 << hshift, C = 1 << shift;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < hh * hw; t += gridDim.x * blockDim.x) {
+        const int i = t / hw, j = t % hw;
+        const int r0 = max(Cc * i - Cc, 0), r1 = min(Cc * i + 2 * Cc - 1, h - 1);
+        const int c0 = Cc * j - Cc, c1 = Cc * j + 2 * Cc - 1;
+        float m = 0.0f;
+        for (int fi = r0 >> shift; fi <= (r1 >> shift); fi++) {
+            if (c1 - c0 + 1 >= w) {                      // the dilated range wraps around the whole map
+                for (int fj = 0; fj < mw; fj++) m = fmaxf(m, mip[(fi + 1) * mp + fj + 1]);
+            } else {
+                for (int c = c0;; c += C) {
+                    const int cc = min(c, c1);
+                    int cw = cc % w; if (cw < 0) cw += w;
+                    m = fmaxf(m, mip[(fi + 1) * mp + (cw >> shift) + 1]);
+                    if (cc == c1) break;
+                }
+            }
+        }
+        out[t] = m;
+    }
+}
+
 // plain max-mip (mh+2) x (mw+2) -> row pairs: element (i, j) = (m[i][j], m[i+1][j]), the last row paired with itself
 __global__ void mip_pair_kernel(const float* __restrict__ mip, float2* __restrict__ out, int rows, int pitch) {
     const int n = rows * pitch;
@@ -1921,6 +2016,12 @@ hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out
 hipError_t mrtx_launch_mip(const float* dem_padded, int h, int w, float* mip, int mh, int mw, int shift, hipStream_t st) {
     hipLaunchKernelGGL(mrtx::mip_build_kernel, dim3(grid_for((int64_t)(mh + 2) * (mw + 2))), dim3(64), 0, st, dem_padded,
                        h, w, mip, mh, mw, shift);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_hmip(const float* mip, int mh, int mw, int shift, float* out, int hh, int hw, int hshift, int h, int w,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::hmip_build_kernel, dim3(grid_for((int64_t)hh * hw)), dim3(64), 0, st, mip, mh, mw, shift, out, hh, hw,
+                       hshift, h, w);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_mip_pairs(const float* mip, float* out_pairs, int rows, int pitch, hipStream_t st) {
