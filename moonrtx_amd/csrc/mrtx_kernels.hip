@@ -142,6 +142,19 @@ __device__ __forceinline__ float lerp2(float e00, float e01, float e10, float e1
 // -2,-1 = columns w-2,w-1, columns w,w+1 = columns 0,1; pitch = w+4), so a bilinear evaluation -- on the march
 // path, where floor() lands in [-1,h-1] x [-1,w-1], and one texel either side of it for the normal -- is two
 // unconditional 8-byte loads: no clamp, no wrap, no seam branch.
+// The hand-over records between render_kernel<MODE 2>, path_kernel and resolve_paths_kernel are written once and read once,
+// 12 GB per cfg-3 frame: NON-TEMPORAL accesses keep them from sweeping the DEM neighbourhoods out of the 4 MB L2s
+// (with plain stores render_kernel<MODE 2> took 17.7 ms against 13.4 without the stores at all).
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float4* p, float a, float b, float c, float d) {
+    v4f v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+}
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct __attribute__((packed, aligned(4))) Pair { float x, y; };
 struct __attribute__((packed, aligned(8))) Quad { float a, b, c, d; };
 struct __attribute__((packed, aligned(8))) UQuad { uint32_t a, b, c, d; };
@@ -1051,7 +1064,10 @@ __device__ __forceinline__ float tree_sum(float v) {
 #endif
 #define MRTX_BOUNCE_WAVES(STATS) ((STATS) ? MRTX_BOUNCE_STATS_WAVES : MRTX_MIN_WAVES_BOUNCE)
 template <int S, bool STATS, bool WIDE, int MODE, bool OVERLAY>
-__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MODE == 1 ? MRTX_BOUNCE_WAVES(STATS) : MRTX_MIN_WAVES)
+#ifndef MRTX_MIN_WAVES_DEFER
+#define MRTX_MIN_WAVES_DEFER 3   // 15.3 ms at cfg3 against 17.1 with 4 and 19.3 with 5 (hand-over stores + cache footprint)
+#endif
+__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MODE == 1 ? MRTX_BOUNCE_WAVES(STATS) : MODE == 2 ? MRTX_MIN_WAVES_DEFER : MRTX_MIN_WAVES)
 render_kernel(const FrameC f, const PathQ pq) {
     constexpr bool DEFER = MODE == 2;
     constexpr int P = 64 / S;
@@ -1134,10 +1150,14 @@ render_kernel(const FrameC f, const PathQ pq) {
                 // (the radiance sum of a pixel needs all S final values, in the spec's order); coverage is final now.
                 const uint32_t chunk = (uint32_t)blockIdx.x * (uint32_t)NJOBS + (uint32_t)job;
                 const uint32_t e = chunk * 64u + (uint32_t)lane;
-                pq.ray0[e] = make_float4(o.path ? o.oa : MRTX_NO_PATH, o.ob, o.oc, o.da);
-                pq.ray1[e] = make_float4(o.db, o.dc, o.t0, o.t1);
-                pq.ray2[e] = make_float4(o.t2, o.row, o.col, __uint_as_float(o.ks));
-                pq.c0[e] = o.c0; pq.c1[e] = o.c1; pq.c2[e] = o.c2;
+#ifndef MRTX_AB_NOSTORE   // A/B only: how much of render_kernel<MODE 2> is the hand-over traffic (results are wrong without it)
+                nt_store4(pq.ray0 + e, o.path ? o.oa : MRTX_NO_PATH, o.ob, o.oc, o.da);
+                nt_store4(pq.ray1 + e, o.db, o.dc, o.t0, o.t1);
+                nt_store4(pq.ray2 + e, o.t2, o.row, o.col, __uint_as_float(o.ks));
+                __builtin_nontemporal_store(o.c0, pq.c0 + e);
+                __builtin_nontemporal_store(o.c1, pq.c1 + e);
+                __builtin_nontemporal_store(o.c2, pq.c2 + e);
+#endif
                 if (lane == 0) pq.meta[chunk] = 0x80000000u | (uint32_t)(px0 + jx * PW) | ((uint32_t)(py0 + jy * PH) << 15);
             } else {
                 s0 += tree_sum<S>(o.c0);
@@ -1313,7 +1333,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                         // one round of loads: the record is read whether or not its chunk was deferred (the arrays
                         // cover every chunk; an undeferred chunk holds stale values that are never used)
                         const uint32_t mt = pq.meta[chunk];
-                        const float4 r0 = pq.ray0[e], r1 = pq.ray1[e], r2 = pq.ray2[e];
+                        const float4 r0 = nt_load4(pq.ray0 + e), r1 = nt_load4(pq.ray1 + e), r2 = nt_load4(pq.ray2 + e);
                         if ((mt & 0x80000000u) && r0.x < 0.5f * MRTX_NO_PATH) {
                             m.rowA = r2.y; m.colA = r2.z;
                             const bool go = march_begin_at<false, STATS>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
@@ -1460,7 +1480,8 @@ __global__ void __launch_bounds__(256) resolve_paths_kernel(const FrameC f, cons
         const uint32_t mt = pq.meta[chunk];
         if (!(mt & 0x80000000u)) continue;
         const uint32_t e = chunk * 64u + lane;
-        const float t0 = tree_sum<S>(pq.c0[e]), t1 = tree_sum<S>(pq.c1[e]), t2 = tree_sum<S>(pq.c2[e]);
+        const float t0 = tree_sum<S>(__builtin_nontemporal_load(pq.c0 + e)), t1 = tree_sum<S>(__builtin_nontemporal_load(pq.c1 + e)),
+                    t2 = tree_sum<S>(__builtin_nontemporal_load(pq.c2 + e));
         const uint32_t pp = lane >> pq.s_log2, ss = lane & ((1u << pq.s_log2) - 1u);
         const uint32_t x = (mt & 0x7FFFu) + (pp & ((1u << pq.pw_log2) - 1u));
         const uint32_t y = ((mt >> 15) & 0x7FFFu) + (pp >> pq.pw_log2);
