@@ -58,7 +58,7 @@ struct mrtx_ctx {
     uint32_t* path_ctr = nullptr;        // 8 x 16 work counters of path_kernel
     int path_nsub = 4, path_grp_log2 = 1;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
-    int path_refill = 8, path_segmin = 24, path_hitmin = 16, path_policy = 0, path_waves_env = 0;
+    int path_refill = 32, path_segmin = 16, path_hitmin = 16, path_policy = 0, path_waves_env = 0;   // cfg3 sweep: (8,24,16) 16.2 ms, (24,24,16) 14.7, (32,16,16) 14.5, (48,24,16) 21.5
     float* accum = nullptr;
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back

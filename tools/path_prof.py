@@ -18,7 +18,7 @@ out = (C.c_ulonglong * 16)()
 settings = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(0, 8, 24, 16)]
 for (pol, refill, segmin, rare) in settings:
     os.environ.update(MOONRT_PATH_POLICY=str(pol), MOONRT_PATH_REFILL=str(refill), MOONRT_PATH_SEGMIN=str(segmin), MOONRT_PATH_HITMIN=str(rare))
-    rt = MoonRT(W, H); rt.bind_dem(dem, dem_h, dem_w); rt.bind_color(col, *col_shape); rt.apply_scene(scene); rt.set_params(flags=0)
+    rt = MoonRT(W, H); rt.bind_dem(dem, dem_h, dem_w); rt.bind_color(col, *col_shape); rt.apply_scene(scene); rt.set_params(flags=int(os.environ.get("FLAGS", "0")))
     rt.render(1); fn(out, 1)
     rt.reset(); st = rt.render(1); fn(out, 1)
     v = list(out)
