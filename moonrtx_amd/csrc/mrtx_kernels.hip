@@ -1213,6 +1213,9 @@ render_kernel(const FrameC f, const PathQ pq) {
 #ifndef MRTX_PATH_WAVES
 #define MRTX_PATH_WAVES 5
 #endif
+#ifndef MRTX_PATH_STEPS
+#define MRTX_PATH_STEPS 2
+#endif
 #ifndef MRTX_PATH_BATCH
 #define MRTX_PATH_BATCH MRTX_STEP_BATCH_BOUNCE
 #endif
@@ -1361,19 +1364,34 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             }
         }
         if (do_step) {
-            // ---- ONE step for every stepping lane
+            // ---- the next MRTX_PATH_STEPS steps of every stepping lane: their DEM footprints are fetched together (one
+            // memory round trip per iteration is what bounds this kernel), then the steps are tested in march order and
+            // whatever follows the one that ends the march or the segment is dropped (its fetch is wasted).  Same
+            // evaluations, same order, same results as one step at a time.  cfg3: 1 step 14.5 ms, 2 steps 13.3.
             if (state == PS_STEP) {
-                const int k = m.ka + j;
-                const float sk = (float)k * f.step;
-                const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
-                const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
-                const bool in = (r2 <= f.R2f) & (k <= f.kmax);
-                const bool bel = below_seg<WIDE, true>(f, sg, sk, pa, pb, pc, r2);
-                if (STATS) { cnt[ST_HEIGHT] += in ? 1u : 0u; cnt[ST_FETCH]++; }
-                j++;
-                if (in & bel) { hit = true; sk_hit = sk; state = PS_ENDED; }
-                else if (!in) state = PS_ENDED;
-                else if (j > sg.jhi) segend = true;
+                bool bel[MRTX_PATH_STEPS], in[MRTX_PATH_STEPS];
+                float sks[MRTX_PATH_STEPS];
+#pragma unroll
+                for (int i = 0; i < MRTX_PATH_STEPS; i++) {
+                    const int k = m.ka + min(j + i, sg.jhi);                 // a step past jhi is read at jhi instead
+                    const float sk = (float)k * f.step;
+                    const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
+                    const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+                    in[i] = (r2 <= f.R2f) & (k <= f.kmax);
+                    bel[i] = below_seg<WIDE, true>(f, sg, sk, pa, pb, pc, r2);
+                    sks[i] = sk;
+                }
+                bool act = true;
+#pragma unroll
+                for (int i = 0; i < MRTX_PATH_STEPS; i++) {
+                    if (act) {
+                        if (STATS) { cnt[ST_HEIGHT] += in[i] ? 1u : 0u; cnt[ST_FETCH]++; }
+                        j++;
+                        if (in[i] & bel[i]) { hit = true; sk_hit = sks[i]; state = PS_ENDED; act = false; }
+                        else if (!in[i]) { state = PS_ENDED; act = false; }
+                        else if (j > sg.jhi) { segend = true; act = false; }
+                    }
+                }
             }
         }
 
