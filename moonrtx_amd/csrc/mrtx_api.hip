@@ -54,9 +54,9 @@ struct mrtx_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> evs;         // stage boundaries of a deferred-path call (3 per block)
     // hand-over records of the deferred path stage (PathQ): 6 float arrays of 64 x chunks + one word per chunk
-    float* path_rec = nullptr; uint32_t* path_meta = nullptr; uint64_t path_cap = 0;
+    float* path_rec = nullptr; uint32_t* path_meta = nullptr; uint8_t* path_npaths = nullptr; uint64_t path_cap = 0;
     uint32_t* path_ctr = nullptr;        // 8 x 16 work counters of path_kernel
-    int path_nsub = 4, path_grp_log2 = 1;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
+    int path_nsub = 4, path_grp_log2 = 3;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
     int path_refill = 32, path_segmin = 16, path_hitmin = 16, path_policy = 0, path_waves_env = 0;   // cfg3 sweep: (8,24,16) 16.2 ms, (24,24,16) 14.7, (32,16,16) 14.5, (48,24,16) 21.5
     float* accum = nullptr;
@@ -490,6 +490,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->stale_dev) (void)hipFree(c->stale_dev);
     if (c->path_rec) (void)hipFree(c->path_rec);
     if (c->path_meta) (void)hipFree(c->path_meta);
+    if (c->path_npaths) (void)hipFree(c->path_npaths);
     if (c->path_ctr) (void)hipFree(c->path_ctr);
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->dem) (void)hipFree(c->dem);
@@ -813,9 +814,11 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         if (chunks > c->path_cap) {
             if (c->path_rec) { HIPCHK(c, hipFree(c->path_rec)); c->path_rec = nullptr; }
             if (c->path_meta) { HIPCHK(c, hipFree(c->path_meta)); c->path_meta = nullptr; }
+            if (c->path_npaths) { HIPCHK(c, hipFree(c->path_npaths)); c->path_npaths = nullptr; }
             c->path_cap = 0;
             if (hipMalloc((void**)&c->path_rec, (size_t)chunks * 64 * MRTX_PATH_REC_BYTES) != hipSuccess ||
-                hipMalloc((void**)&c->path_meta, (size_t)chunks * sizeof(uint32_t)) != hipSuccess) {
+                hipMalloc((void**)&c->path_meta, (size_t)chunks * sizeof(uint32_t)) != hipSuccess ||
+                hipMalloc((void**)&c->path_npaths, (size_t)chunks + 64) != hipSuccess) {
                 (void)hipGetLastError();
                 return fail(c, MRTX_E_NOMEM, "no device memory for %llu path records (%.1f GB); MRTX_F_INWAVE_PATHS needs none",
                             (unsigned long long)(chunks * 64), (double)chunks * 64 * MRTX_PATH_REC_BYTES / 1e9);
@@ -825,6 +828,8 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         const size_t n = (size_t)chunks * 64;
         pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
         pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n;
+        pq.lane_of = reinterpret_cast<uint8_t*>(pq.c2 + n);
+        pq.npaths = c->path_npaths;
         pq.meta = c->path_meta;
         if (!c->path_ctr) HIPCHK(c, hipMalloc((void**)&c->path_ctr, 8 * 16 * sizeof(uint32_t)));
         pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
@@ -847,6 +852,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             fb.n_blocks = 1;
             pq.gs_base = fb.first_block * (uint32_t)S;
             HIPCHK(c, hipMemsetAsync(c->path_meta, 0, (size_t)chunks * sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->path_npaths, 0, (size_t)chunks, c->stream));
             HIPCHK(c, hipMemsetAsync(c->path_ctr, 0, 8 * 16 * sizeof(uint32_t), c->stream));
             HIPCHK(c, hipEventRecord(c->evs[(size_t)b * 3], c->stream));
             HIPCHK(c, mrtx_launch_render(fb, S, stats, 2, overlay, &pq, c->stream));

@@ -108,8 +108,9 @@ struct FrameC {
 
 // Hand-over between render_kernel<MODE 2> (camera ray, first vertex, its direct light, the decision to go on) and
 // path_kernel (everything after), one RECORD per lane of every wave-job ("chunk") of the render launch:
-//   ray0/1/2  float4 each: continuation-ray origin (3; ray0.x = MRTX_NO_PATH: this sample has no path to continue),
-//             direction (3), path throughput (3), exact DEM texel coordinates of the origin (2), RNG key of the sample (1)
+//   ray0/1/2  float4 each, only for the samples whose path goes on, compacted to the front of the chunk (npaths[chunk] of
+//             them, lane_of[] says whose): continuation-ray origin (3), direction (3), path throughput (3), exact DEM texel
+//             coordinates of the origin (2), RNG key of the sample (1)
 //   c0/1/2    the sample's radiance so far (direct term / Sun disk / environment / overlay colour); path_kernel writes
 //             the final value back when the path adds light, resolve_paths_kernel sums the 64 lanes in the butterfly
 //             order of the spec
@@ -118,6 +119,8 @@ struct FrameC {
 struct PathQ {
     float4* ray0; float4* ray1; float4* ray2;
     float* c0; float* c1; float* c2;
+    uint8_t* lane_of;           // per ray record: the lane (sample) of its chunk it belongs to
+    uint8_t* npaths;            // per chunk: ray records it holds (0 for a chunk that was not deferred): zero before the launch
     uint32_t* meta;
     uint32_t n_chunks;          // wave-jobs of the render launch (grid x jobs per wave)
     uint32_t grid_a;            // blocks of the render launch; chunk = block * jobs + job
@@ -132,5 +135,5 @@ struct PathQ {
     int32_t rare_min;           // ... and runs the rare steps (a continuation ray hit terrain; a vertex got its direct
                                 //     term) when at least this many lanes wait for them
 };
-#define MRTX_PATH_REC_BYTES 60  // per record: 3 x float4 + 3 x float
+#define MRTX_PATH_REC_BYTES 61  // per record: 3 x float4 + 3 x float + 1 byte
 #define MRTX_NO_PATH 1.0e30f

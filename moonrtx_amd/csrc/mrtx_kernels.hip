@@ -29,6 +29,10 @@
 // (wave-uniform) reads become scalar loads (s_load_*) instead of per-lane vector loads.
 #define CF(f) ((const __attribute__((address_space(4))) FrameCold*)(f).cold)
 
+#ifndef MRTX_TRIAL_SEGMENT
+#define MRTX_TRIAL_SEGMENT 1   // 0 = hand every continuation ray to path_kernel unmarched (A/B switch, see trace_sample)
+#endif
+
 namespace mrtx {
 
 __device__ constexpr float kPi = 3.14159274101257324f;
@@ -999,8 +1003,36 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 exact_rowcol(f, o.oa, o.ob, o.oc, o.row, o.col, q2);
                 o.t0 = t0r; o.t1 = t1r; o.t2 = t2r;
                 o.ks = ks;
-                o.path = true;
                 if (STATS) cnt[ST_BOUNCE]++;
+#if MRTX_TRIAL_SEGMENT
+                // The FIRST segment of the continuation ray is marched right here: the 64 rays of the pixel still start
+                // within a texel of each other, every lane is busy, and four rays in five end inside it without touching
+                // the terrain again (they have cleared everything in reach, horizon_kend, or left the shell) -- those paths
+                // are finished in this wave.  A ray that hits, or is still marching after 16 steps, goes to path_kernel,
+                // which marches it from its origin (so its evaluations are counted there, not here).
+                uint32_t tcnt[ST_N];
+                if (STATS) {
+#pragma unroll
+                    for (int i = 0; i < ST_N; i++) tcnt[i] = 0;
+                }
+                MarchState tm;
+                tm.rowA = o.row; tm.colA = o.col;
+                bool tgo = march_begin_at<false, STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, tm, tcnt), thit = false;
+                Seg tsg;
+                float tsk = 0.0f;
+                if (tgo) march_segment<WIDE, false, STATS, BATCH>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
+                if (!tgo && !thit) {
+                    escaped_path<STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, t0r, t1r, t2r, o.c0, o.c1, o.c2, cnt);
+                    if (STATS) {
+#pragma unroll
+                        for (int i = 0; i < ST_N; i++) cnt[i] += tcnt[i];
+                    }
+                } else {
+                    o.path = true;
+                }
+#else
+                o.path = true;
+#endif
             }
         }
         if (!BOUNCE) break;
@@ -1150,14 +1182,22 @@ render_kernel(const FrameC f, const PathQ pq) {
                 // (the radiance sum of a pixel needs all S final values, in the spec's order); coverage is final now.
                 const uint32_t chunk = (uint32_t)blockIdx.x * (uint32_t)NJOBS + (uint32_t)job;
                 const uint32_t e = chunk * 64u + (uint32_t)lane;
+                // ray records: only the lanes whose path goes on, COMPACTED to the front of the chunk (npaths says how many;
+                // lane_of maps a record back to its sample); the running radiance of all 64 samples in lane order
+                const uint64_t pm = __ballot(o.path);
+                const uint32_t es = chunk * 64u + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
 #ifndef MRTX_AB_NOSTORE   // A/B only: how much of render_kernel<MODE 2> is the hand-over traffic (results are wrong without it)
-                nt_store4(pq.ray0 + e, o.path ? o.oa : MRTX_NO_PATH, o.ob, o.oc, o.da);
-                nt_store4(pq.ray1 + e, o.db, o.dc, o.t0, o.t1);
-                nt_store4(pq.ray2 + e, o.t2, o.row, o.col, __uint_as_float(o.ks));
+                if (o.path) {
+                    nt_store4(pq.ray0 + es, o.oa, o.ob, o.oc, o.da);
+                    nt_store4(pq.ray1 + es, o.db, o.dc, o.t0, o.t1);
+                    nt_store4(pq.ray2 + es, o.t2, o.row, o.col, __uint_as_float(o.ks));
+                    pq.lane_of[es] = (uint8_t)lane;
+                }
                 __builtin_nontemporal_store(o.c0, pq.c0 + e);
                 __builtin_nontemporal_store(o.c1, pq.c1 + e);
                 __builtin_nontemporal_store(o.c2, pq.c2 + e);
 #endif
+                if (lane == 0) pq.npaths[chunk] = (uint8_t)__popcll(pm);
                 if (lane == 0) pq.meta[chunk] = 0x80000000u | (uint32_t)(px0 + jx * PW) | ((uint32_t)(py0 + jy * PH) << 15);
             } else {
                 s0 += tree_sum<S>(o.c0);
@@ -1246,9 +1286,13 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     const uint32_t sub = (blockIdx.x >> 3) % (uint32_t)pq.n_sub;
     uint32_t* const ctr = pq.counters + label * (uint32_t)pq.n_sub + sub;
     const uint32_t npos = (pq.grid_a + 7u) >> 3;                     // render blocks per label
-    const uint32_t grp_recs = 64u << (pq.grp_log2 + pq.njobs_log2);   // records in a group
-    uint32_t grp_first = 0, grp_used = grp_recs;                      // first block position of the current group; records taken
+    const uint32_t cpg = 1u << (pq.grp_log2 + pq.njobs_log2);         // chunks in a group (<= 64)
+    // current group: first block position, chunk being read, records taken from it / it holds; lane i < cpg keeps the
+    // record count of the group's chunk i.  The NEXT group's number is fetched (atomic) while this one is consumed.
+    uint32_t grp_first = 0, cidx = cpg, pos = 0, ncur = 0, gcnt = 0;
     bool more = npos > 0;                                             // groups may be left
+    uint32_t next_g = 0;
+    if (lane == 0 && more) next_g = atomicAdd(ctr, 1u);
     uint32_t iterations = 0;
     uint32_t cnt[ST_N];
     if (STATS) {
@@ -1316,39 +1360,48 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
 
         bool segend = false;
         if (do_refill) {
-            // ---- refill: idle lanes take the next records of the wave's current group (a new group when it is used up)
-            if (grp_used >= grp_recs) {
-                uint32_t g = 0;
-                if (lane == 0) g = atomicAdd(ctr, 1u);
-                g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-                grp_first = (g * (uint32_t)pq.n_sub + sub) << pq.grp_log2;
-                grp_used = 0;
-                more = grp_first < npos;
-            }
-            if (more) {
-                if (state == PS_IDLE) {
-                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                    const uint32_t vi = grp_used + r;
-                    const uint32_t blk = ((grp_first + (vi >> (6 + pq.njobs_log2))) << 3) + label;
-                    if (vi < grp_recs && blk < pq.grid_a) {
-                        const uint32_t chunk = (blk << pq.njobs_log2) + ((vi >> 6) & ((1u << pq.njobs_log2) - 1u));
-                        e = chunk * 64u + (vi & 63u);
-                        // one round of loads: the record is read whether or not its chunk was deferred (the arrays
-                        // cover every chunk; an undeferred chunk holds stale values that are never used)
-                        const uint32_t mt = pq.meta[chunk];
-                        const float4 r0 = nt_load4(pq.ray0 + e), r1 = nt_load4(pq.ray1 + e), r2 = nt_load4(pq.ray2 + e);
-                        if ((mt & 0x80000000u) && r0.x < 0.5f * MRTX_NO_PATH) {
-                            m.rowA = r2.y; m.colA = r2.z;
-                            const bool go = march_begin_at<false, STATS>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
-                            t0r = r1.z; t1r = r1.w; t2r = r2.x;
-                            ks = __float_as_uint(r2.w);
-                            hit = false; shadow = false; have_c = false;
-                            seg = 1;
-                            state = go ? PS_NEEDSEG : PS_ENDED;
+            // ---- refill: idle lanes take the next ray records of the wave's current group, chunk after chunk (a chunk
+            // holds npaths[chunk] of them, compacted); wave-uniform bookkeeping, one fetch round for the lanes that got one
+            const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+            uint32_t need = (uint32_t)nidle, assigned = 0;
+            bool fill_l = false;
+            while (need > 0 && more) {
+                if (pos >= ncur) {                       // next chunk, or next group
+                    cidx++;
+                    if (cidx >= cpg) {
+                        const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_g);
+                        grp_first = (g * (uint32_t)pq.n_sub + sub) << pq.grp_log2;
+                        more = grp_first < npos;
+                        if (!more) break;
+                        if (lane == 0) next_g = atomicAdd(ctr, 1u);
+                        gcnt = 0;
+                        if (lane < cpg) {
+                            const uint32_t blk = ((grp_first + (lane >> pq.njobs_log2)) << 3) + label;
+                            if (blk < pq.grid_a) gcnt = pq.npaths[(blk << pq.njobs_log2) + (lane & ((1u << pq.njobs_log2) - 1u))];
                         }
+                        cidx = 0;
                     }
+                    ncur = (uint32_t)__builtin_amdgcn_readlane((int)gcnt, (int)cidx);
+                    pos = 0;
+                    continue;
                 }
-                grp_used += (uint32_t)nidle;
+                const uint32_t take = min(need, ncur - pos);
+                if (state == PS_IDLE && !fill_l && r >= assigned && r < assigned + take) {
+                    const uint32_t blk = ((grp_first + (cidx >> pq.njobs_log2)) << 3) + label;
+                    e = (((blk << pq.njobs_log2) + (cidx & ((1u << pq.njobs_log2) - 1u))) << 6) + pos + (r - assigned);
+                    fill_l = true;
+                }
+                pos += take; assigned += take; need -= take;
+            }
+            if (fill_l) {
+                const float4 r0 = nt_load4(pq.ray0 + e), r1 = nt_load4(pq.ray1 + e), r2 = nt_load4(pq.ray2 + e);
+                m.rowA = r2.y; m.colA = r2.z;
+                const bool go = march_begin_at<false, STATS>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
+                t0r = r1.z; t1r = r1.w; t2r = r2.x;
+                ks = __float_as_uint(r2.w);
+                hit = false; shadow = false; have_c = false;
+                seg = 1;
+                state = go ? PS_NEEDSEG : PS_ENDED;
             }
         }
         if (do_seg) {
@@ -1421,7 +1474,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 // the path left the Moon: Sun disk / environment along the ray, if there is any
                 float e0, e1, e2;
                 if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {
-                    if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                    if (!have_c) { e = (e & ~63u) | (uint32_t)pq.lane_of[e]; c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
                     c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
                 }
                 if (have_c) { pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2; }
@@ -1434,7 +1487,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         // continued or ended (~250 VALU).  They wait until enough lanes need them -- or nothing is marching.
         if (do_rare) {
             if (state == PS_HITWAIT) {
-                if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                if (!have_c) { e = (e & ~63u) | (uint32_t)pq.lane_of[e]; c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
                 const int bk = (int)rintf(sk_hit * f.inv_step);
                 float blo = (float)(bk - 1) * f.step, bhi = sk_hit;
                 refine<WIDE>(f, sg, m.oa, m.ob, m.oc, m.da, m.db, m.dc, blo, bhi);
