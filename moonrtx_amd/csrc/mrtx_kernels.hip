@@ -29,6 +29,9 @@
 // (wave-uniform) reads become scalar loads (s_load_*) instead of per-lane vector loads.
 #define CF(f) ((const __attribute__((address_space(4))) FrameCold*)(f).cold)
 
+#ifndef MRTX_TRIAL_BATCH
+#define MRTX_TRIAL_BATCH 2     // steps fetched together in the trial segment
+#endif
 #ifndef MRTX_TRIAL_SEGMENT
 #define MRTX_TRIAL_SEGMENT 1   // 0 = hand every continuation ray to path_kernel unmarched (A/B switch, see trace_sample)
 #endif
@@ -1020,7 +1023,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 bool tgo = march_begin_at<false, STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, tm, tcnt), thit = false;
                 Seg tsg;
                 float tsk = 0.0f;
-                if (tgo) march_segment<WIDE, false, STATS, BATCH>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
+                if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
                 if (!tgo && !thit) {
                     escaped_path<STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, t0r, t1r, t2r, o.c0, o.c1, o.c2, cnt);
                     if (STATS) {
