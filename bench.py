@@ -260,6 +260,24 @@ def main():
         rt.apply_scene(scene)
         rt.set_params(flags=base_flags)
 
+    # ... and the close-up the reference's user actually looks at most of the time: the same frame size and DEM, camera
+    # turned onto the terminator, field of view 0.7 deg (every pixel of the frame is on the Moon)
+    zoom = None
+    if world == 1 and seg[1] > 1 and not args.no_secondary:
+        from moonrtx_amd.scene import zoomed_on_terminator
+        zs = zoomed_on_terminator(args.scene, W, H, vfov_deg=0.7, spp_per_launch=S)
+        zs.max_spp = spp
+        zs.path_seg_min, zs.path_seg_max = seg
+        rt.apply_scene(zs)
+        rt.set_params(flags=base_flags)
+        step()
+        e3, k3 = timed(3)
+        zoom = {"scene": f"{args.scene} zoomed on the terminator, vfov 0.7 deg, path_seg_range {list(seg)}",
+                "value": round(W * H * spp / (e3 / 3) / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(e3 / 3 * 1e3, 3),
+                "kernel_ms": round(k3["kernel_ms"], 3), "primary_ms": round(k3["primary_ms"], 3), "paths_ms": round(k3["paths_ms"], 3)}
+        rt.apply_scene(scene)
+        rt.set_params(flags=base_flags)
+
     facade = None
     if rank == 0 and world == 1 and args.workload == "cfg3" and not args.no_secondary:
         try:
@@ -363,6 +381,8 @@ def main():
         }
         if also is not None:
             out["also"] = also
+        if zoom is not None:
+            out["also_zoomed"] = zoom
         if facade is not None:
             out["facade"] = facade
         if world == 1 and not args.no_cpu_baseline:

@@ -180,3 +180,20 @@ SCENES = {
 
 def named_scene(name, width, height, **kw):
     return make_scene(width, height, **SCENES[name], **kw)
+
+
+def zoomed_on_terminator(name, width, height, vfov_deg=0.7, **kw):
+    """The interactive close-up the reference spends its time in (zoom / pan, renderer_navigation.py:226-521): scene `name`
+    with the default camera turned onto the point of the terminator nearest the disc centre and the field of view
+    narrowed to `vfov_deg` (the whole-disc view is 4.24 deg; at 0.7 deg a 4K pixel covers ~1.2 texels of a
+    downscale-2 DEM)."""
+    s = named_scene(name, width, height, **kw)
+    light = np.asarray(s.light_pos, float) - np.asarray(s.center, float)
+    light /= np.linalg.norm(light)
+    to_eye = np.asarray(s.eye, float) - np.asarray(s.center, float)
+    to_eye /= np.linalg.norm(to_eye)
+    n = to_eye - (to_eye @ light) * light            # on the terminator (n . light = 0), as much toward the camera as possible
+    n /= np.linalg.norm(n)
+    s.target = tuple(np.asarray(s.center, float) + s.radius * n)
+    s.vfov_deg = float(vfov_deg)
+    return s

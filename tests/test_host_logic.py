@@ -75,3 +75,15 @@ def test_helper_scripts_parse():
         py_compile.compile(path, doraise=True)
     for path in sorted(glob.glob(os.path.join(root, "tools", "*.sh"))):
         assert subprocess.run(["bash", "-n", path]).returncode == 0, path
+
+
+def test_zoomed_scene_looks_at_the_terminator():
+    """bench.py's close-up: the camera target lies on the terminator (normal perpendicular to the light) on the near side."""
+    import numpy as np
+    from moonrtx_amd import scene as sc
+    for name in ("S1", "S2", "S3"):
+        s = sc.zoomed_on_terminator(name, 640, 360)
+        n = np.asarray(s.target) / sc.MOON_RADIUS
+        light = np.asarray(s.light_pos) / np.linalg.norm(s.light_pos)
+        assert abs(np.linalg.norm(n) - 1.0) < 1e-12 and abs(n @ light) < 1e-12
+        assert n @ (np.asarray(s.eye) / np.linalg.norm(s.eye)) > 0.0 and s.vfov_deg == 0.7
