@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--dem-scale", type=int, default=1, help="debug: shrink the DEM by this factor")
     ap.add_argument("--path-seg", type=int, nargs=2, default=(2, 4), metavar=("MIN", "MAX"),
                     help="path length in segments; (2,4) is what the reference sets (headline), (1,1) = direct light only")
+    ap.add_argument("--zoom", type=float, default=0.0, metavar="VFOV_DEG",
+                    help="profiling aid: make the zoomed terminator view (this vertical field of view) the timed scene")
     ap.add_argument("--inwave-paths", action="store_true", help="A/B: keep D6 paths inside the render wave (MRTX_F_INWAVE_PATHS)")
     args = ap.parse_args()
 
@@ -187,6 +189,9 @@ def main():
     t_inputs = time.perf_counter() - t0
 
     scene = named_scene(args.scene, W, H, spp_per_launch=S)
+    if args.zoom > 0.0:
+        from moonrtx_amd.scene import zoomed_on_terminator
+        scene = zoomed_on_terminator(args.scene, W, H, vfov_deg=args.zoom, spp_per_launch=S)
     scene.max_spp = spp
     scene.path_seg_min, scene.path_seg_max = seg
     rt = MoonRT(W, H, device=dev, rank=rank, world=world)
@@ -361,7 +366,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {W}x{H}, {spp} spp, DEM {dem_h}x{dem_w} f32"
                                    + (f", colour {col_shape[0]}x{col_shape[1]} RGBA8" if col_shape else ", grey albedo")
-                                   + f", scene {args.scene}, path_seg_range {seg}"
+                                   + f", scene {args.scene}" + (f" zoomed on the terminator (vfov {args.zoom} deg)" if args.zoom > 0 else "")
+                                   + f", path_seg_range {seg}"
                                    + (" = the reference's setting (moon_renderer.py:583)" if seg == (2, 4) else ""),
                        "parallelism": f"image tiles 32x32 dealt round-robin (2-D lattice) over {world} GPU(s), active tiles gathered to rank 0"
                                       + (", RCCL gather of float4 radiance+hits to rank 0" if world > 1 else ""),
