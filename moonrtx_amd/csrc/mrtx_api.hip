@@ -244,7 +244,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     f.tile_w = c->cfg.tile_w; f.tile_h = c->cfg.tile_h;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.tile_shift = c->tile_shift;
     f.rank = c->cfg.rank; f.world = c->cfg.world; f.n_local_tiles = c->n_local;
-    f.accum = c->accum; f.hits = c->hits; f.stats = c->stats_dev;
+    k.accum = c->accum; k.hits = c->hits; k.stats = c->stats_dev;
     f.tile_list = nullptr; f.n_active = c->n_local;
 }
 

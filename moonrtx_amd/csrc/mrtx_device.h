@@ -72,6 +72,11 @@ struct FrameCold {
     const int32_t* caps_off;   // n_local_tiles + 1
     const int32_t* caps_idx;
     int32_t n_caps;
+    // output buffers: touched once per pixel, at the end of a wave's life -- kept out of the by-value block so that they do
+    // not occupy SGPRs (and get spilled) across the march loops
+    float* accum;           // W*H float4: running sums r,g,b,coverage
+    float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block
+    unsigned long long* stats;  // 10 counters, see MrtxStats
     // horizon mip (horizon_kend in mrtx_kernels.hip): hm_h x hm_w cells of 2^hm_shift texels, or null
     const float* hmip;
     int32_t hm_h, hm_w, hm_shift;
@@ -101,9 +106,6 @@ struct FrameC {
 
     int32_t xcd_share;      // 1: every tile is shared by the 8 XCDs (few tiles per launch), 0: whole tiles per XCD
     uint32_t first_block, n_blocks;
-    float* accum;           // W*H float4: running sums r,g,b,coverage
-    float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block
-    unsigned long long* stats;  // 10 counters, see MrtxStats
 };
 
 // Hand-over between render_kernel<MODE 2> (camera ray, first vertex, its direct light, the decision to go on) and

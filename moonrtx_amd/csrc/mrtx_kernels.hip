@@ -1166,7 +1166,7 @@ render_kernel(const FrameC f, const PathQ pq) {
         const int64_t pix = (int64_t)y * f.W + x;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (f.first_block != 0 && inb) {
-            const float4 prev = reinterpret_cast<const float4*>(f.accum)[pix];
+            const float4 prev = reinterpret_cast<const float4*>(CF(f)->accum)[pix];
             s0 = prev.x; s1 = prev.y; s2 = prev.z; s3 = prev.w;
         }
         SampleOut o;
@@ -1210,8 +1210,8 @@ render_kernel(const FrameC f, const PathQ pq) {
             s3 += tree_sum<S>(o.hitflag);
         }
         if (inb && s == 0) {
-            reinterpret_cast<float4*>(f.accum)[pix] = make_float4(s0, s1, s2, s3);
-            reinterpret_cast<float4*>(f.hits)[pix] = make_float4(o.h0, o.h1, o.h2, o.h3);
+            reinterpret_cast<float4*>(CF(f)->accum)[pix] = make_float4(s0, s1, s2, s3);
+            reinterpret_cast<float4*>(CF(f)->hits)[pix] = make_float4(o.h0, o.h1, o.h2, o.h3);
         }
     }
 
@@ -1231,7 +1231,7 @@ render_kernel(const FrameC f, const PathQ pq) {
             if (lane == 0) atomicAdd(&lds_cnt[i], v);
         }
         __syncthreads();
-        if (threadIdx.x < ST_N) atomicAdd(&f.stats[threadIdx.x], (unsigned long long)lds_cnt[threadIdx.x]);
+        if (threadIdx.x < ST_N) atomicAdd(&CF(f)->stats[threadIdx.x], (unsigned long long)lds_cnt[threadIdx.x]);
     }
 }
 
@@ -1333,7 +1333,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         const bool can_refill = more;
         if (nidle == 64 && !can_refill) break;   // every path of this wave is finished and no work is left: the regular exit
         if (++iterations > (1u << 24)) {         // watchdog: far beyond any real frame (~1e4 iterations); never hang the GPU
-            if (lane == 0) atomicAdd(&f.stats[15], 1ull);
+            if (lane == 0) atomicAdd(&CF(f)->stats[15], 1ull);
             break;
         }
         const int n_seg = __popcll(__ballot(state == PS_NEEDSEG)), n_step = __popcll(__ballot(state == PS_STEP));
@@ -1540,7 +1540,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             uint32_t t = cnt[i];
 #pragma unroll
             for (int k = 1; k < 64; k <<= 1) t += __shfl_xor(t, k, 64);
-            if (lane == 0 && t != 0u) atomicAdd(&f.stats[i], (unsigned long long)t);
+            if (lane == 0 && t != 0u) atomicAdd(&CF(f)->stats[i], (unsigned long long)t);
         }
     }
 }
@@ -1560,7 +1560,7 @@ __global__ void __launch_bounds__(256) resolve_paths_kernel(const FrameC f, cons
         const uint32_t x = (mt & 0x7FFFu) + (pp & ((1u << pq.pw_log2) - 1u));
         const uint32_t y = ((mt >> 15) & 0x7FFFu) + (pp >> pq.pw_log2);
         if (ss == 0u && x < (uint32_t)f.W && y < (uint32_t)f.H) {
-            float4* a = reinterpret_cast<float4*>(f.accum) + ((int64_t)y * f.W + x);
+            float4* a = reinterpret_cast<float4*>(CF(f)->accum) + ((int64_t)y * f.W + x);
             float4 t = *a;
             t.x += t0; t.y += t1; t.z += t2;
             *a = t;
