@@ -56,6 +56,7 @@ struct mrtx_ctx {
     // hand-over records of the deferred path stage (PathQ): 6 float arrays of 64 x chunks + one word per chunk
     float* path_rec = nullptr; uint32_t* path_meta = nullptr; uint8_t* path_npaths = nullptr; uint64_t path_cap = 0;
     uint32_t* path_ctr = nullptr;        // 8 x 16 work counters of path_kernel
+    uint64_t path_budget_bytes = 24ull << 30;   // hand-over buffers: frames that need more are rendered in sub-parts (MOONRT_PATH_MAX_GB)
     int path_nsub = 4, path_grp_log2 = 3;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
     int path_refill = 32, path_segmin = 16, path_hitmin = 16, path_policy = 0, path_waves_env = 0;   // cfg3 sweep: (8,24,16) 16.2 ms, (24,24,16) 14.7, (32,16,16) 14.5, (48,24,16) 21.5
@@ -445,6 +446,7 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
         if ((e = std::getenv("MOONRT_PATH_HITMIN")) && std::atoi(e) >= -64 && std::atoi(e) <= 64) c->path_hitmin = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_NSUB")) && std::atoi(e) >= 1 && std::atoi(e) <= 16) c->path_nsub = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_GRP")) && std::atoi(e) >= 0 && std::atoi(e) <= 10) c->path_grp_log2 = std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_MAX_GB")) && std::atof(e) > 0.0) c->path_budget_bytes = (uint64_t)(std::atof(e) * 1073741824.0);
         if ((e = std::getenv("MOONRT_PATH_POLICY"))) c->path_policy = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_WAVES")) && std::atoi(e) >= 8) c->path_waves_env = std::atoi(e) / 8 * 8;
     }
@@ -807,9 +809,26 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         primary_ms = ms;
         launches = 1;
     } else {
-        PathQ pq;
-        std::memset(&pq, 0, sizeof pq);
-        const uint64_t chunks = mrtx_path_chunks(f, S, &pq.grid_a, &pq.njobs_log2);
+        // The hand-over buffers are sized for the worst case (61 bytes for each of the 64 lanes of every wave-job of the
+        // launch: 12 GB for the whole-disc cfg3 frame, 129 GB for a cfg4 frame whose every pixel is on the Moon).  A frame
+        // that needs more than path_budget_bytes is rendered in SUB-PARTS of its tile list, one after the other through the
+        // same buffers: render(sub) -> paths(sub) -> resolve(sub); sub-parts cover disjoint pixels.
+        const uint64_t cap_chunks = std::max<uint64_t>(4096, c->path_budget_bytes / (64ull * MRTX_PATH_REC_BYTES));
+        int n_sub = 1;
+        {
+            const uint64_t full = mrtx_path_chunks(f, S, nullptr, nullptr);
+            if (full > cap_chunks && f.tile_list != nullptr) n_sub = (int)std::min<uint64_t>((uint64_t)f.n_active, (full + cap_chunks - 1) / cap_chunks);
+        }
+        std::vector<FrameC> fs((size_t)n_sub, f);
+        std::vector<PathQ> pqs((size_t)n_sub);
+        uint64_t chunks = 0;
+        for (int s = 0; s < n_sub; s++) {
+            int a_, b_;
+            part_range(f.n_active, s, n_sub, a_, b_);
+            if (n_sub > 1) { fs[(size_t)s].tile_list = f.tile_list + a_; fs[(size_t)s].n_active = b_ - a_; }
+            std::memset(&pqs[(size_t)s], 0, sizeof(PathQ));
+            chunks = std::max(chunks, mrtx_path_chunks(fs[(size_t)s], S, &pqs[(size_t)s].grid_a, &pqs[(size_t)s].njobs_log2));
+        }
         if (chunks * 64ull > 0xFFFFFFFFull) return fail(c, MRTX_E_INVALID, "frame too large for one deferred-path launch (%llu chunks)", (unsigned long long)chunks);
         if (chunks > c->path_cap) {
             if (c->path_rec) { HIPCHK(c, hipFree(c->path_rec)); c->path_rec = nullptr; }
@@ -825,19 +844,22 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             }
             c->path_cap = chunks;
         }
-        const size_t n = (size_t)chunks * 64;
-        pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
-        pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n;
-        pq.lane_of = reinterpret_cast<uint8_t*>(pq.c2 + n);
-        pq.npaths = c->path_npaths;
-        pq.meta = c->path_meta;
+        const size_t n = (size_t)c->path_cap * 64;
         if (!c->path_ctr) HIPCHK(c, hipMalloc((void**)&c->path_ctr, 8 * 16 * sizeof(uint32_t)));
-        pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
-        pq.n_chunks = (uint32_t)chunks;
-        pq.s_log2 = 0;
-        while ((1 << pq.s_log2) < S) pq.s_log2++;
-        { const int P = 64 / S; const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1; pq.pw_log2 = PW == 8 ? 3 : PW == 4 ? 2 : PW == 2 ? 1 : 0; }
-        pq.refill_min = c->path_refill; pq.seg_min = c->path_segmin; pq.rare_min = c->path_hitmin; pq.policy = c->path_policy;
+        for (int s = 0; s < n_sub; s++) {
+            PathQ& pq = pqs[(size_t)s];
+            pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
+            pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n;
+            pq.lane_of = reinterpret_cast<uint8_t*>(pq.c2 + n);
+            pq.npaths = c->path_npaths;
+            pq.meta = c->path_meta;
+            pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
+            pq.n_chunks = (uint32_t)((uint64_t)pq.grid_a << pq.njobs_log2);
+            pq.s_log2 = 0;
+            while ((1 << pq.s_log2) < S) pq.s_log2++;
+            { const int P = 64 / S; const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1; pq.pw_log2 = PW == 8 ? 3 : PW == 4 ? 2 : PW == 2 ? 1 : 0; }
+            pq.refill_min = c->path_refill; pq.seg_min = c->path_segmin; pq.rare_min = c->path_hitmin; pq.policy = c->path_policy;
+        }
         const int wi = (stats ? 2 : 0) + (f.dem_wide ? 1 : 0);
         if (c->path_waves[wi] == 0) {
             int nw = 0;
@@ -845,20 +867,25 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             c->path_waves[wi] = nw;
         }
         const int nw = c->path_waves_env ? c->path_waves_env : c->path_waves[wi];
-        while (c->evs.size() < (size_t)n_blocks * 3) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->evs.push_back(e); }
+        const size_t n_ev = (size_t)n_blocks * (size_t)n_sub * 3;
+        while (c->evs.size() < n_ev) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->evs.push_back(e); }
         for (int32_t b = 0; b < n_blocks; b++) {
-            FrameC fb = f;
-            fb.first_block = c->blocks_done + (uint32_t)b;
-            fb.n_blocks = 1;
-            pq.gs_base = fb.first_block * (uint32_t)S;
-            HIPCHK(c, hipMemsetAsync(c->path_meta, 0, (size_t)chunks * sizeof(uint32_t), c->stream));
-            HIPCHK(c, hipMemsetAsync(c->path_npaths, 0, (size_t)chunks, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->path_ctr, 0, 8 * 16 * sizeof(uint32_t), c->stream));
-            HIPCHK(c, hipEventRecord(c->evs[(size_t)b * 3], c->stream));
-            HIPCHK(c, mrtx_launch_render(fb, S, stats, 2, overlay, &pq, c->stream));
-            HIPCHK(c, hipEventRecord(c->evs[(size_t)b * 3 + 1], c->stream));
-            HIPCHK(c, mrtx_launch_paths(fb, pq, S, stats, nw, c->stream));
-            HIPCHK(c, hipEventRecord(c->evs[(size_t)b * 3 + 2], c->stream));
+            for (int s = 0; s < n_sub; s++) {
+                hipEvent_t* ev = &c->evs[((size_t)b * (size_t)n_sub + (size_t)s) * 3];
+                FrameC fb = fs[(size_t)s];
+                fb.first_block = c->blocks_done + (uint32_t)b;
+                fb.n_blocks = 1;
+                PathQ& pq = pqs[(size_t)s];
+                pq.gs_base = fb.first_block * (uint32_t)S;
+                HIPCHK(c, hipMemsetAsync(c->path_meta, 0, (size_t)pq.n_chunks * sizeof(uint32_t), c->stream));
+                HIPCHK(c, hipMemsetAsync(c->path_npaths, 0, (size_t)pq.n_chunks, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->path_ctr, 0, 8 * 16 * sizeof(uint32_t), c->stream));
+                HIPCHK(c, hipEventRecord(ev[0], c->stream));
+                HIPCHK(c, mrtx_launch_render(fb, S, stats, 2, overlay, &pq, c->stream));
+                HIPCHK(c, hipEventRecord(ev[1], c->stream));
+                HIPCHK(c, mrtx_launch_paths(fb, pq, S, stats, nw, c->stream));
+                HIPCHK(c, hipEventRecord(ev[2], c->stream));
+            }
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         {   // path_kernel's watchdog (stats[15]): a wave gave up after 2^24 iterations -- the frame is incomplete
@@ -869,13 +896,13 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
                 return fail(c, MRTX_E_DEVICE, "path_kernel watchdog: %llu wave(s) did not finish their paths", wd);
             }
         }
-        for (int32_t b = 0; b < n_blocks; b++) {
+        for (size_t i = 0; i < (size_t)n_blocks * (size_t)n_sub; i++) {
             float a = 0.0f, p = 0.0f;
-            HIPCHK(c, hipEventElapsedTime(&a, c->evs[(size_t)b * 3], c->evs[(size_t)b * 3 + 1]));
-            HIPCHK(c, hipEventElapsedTime(&p, c->evs[(size_t)b * 3 + 1], c->evs[(size_t)b * 3 + 2]));
+            HIPCHK(c, hipEventElapsedTime(&a, c->evs[i * 3], c->evs[i * 3 + 1]));
+            HIPCHK(c, hipEventElapsedTime(&p, c->evs[i * 3 + 1], c->evs[i * 3 + 2]));
             primary_ms += a; paths_ms += p;
         }
-        launches = 3u * (uint32_t)n_blocks;
+        launches = 3u * (uint32_t)n_blocks * (uint32_t)n_sub;
     }
     if (part == n_parts - 1) c->blocks_done += (uint32_t)n_blocks;
     if (out) {

@@ -4,7 +4,7 @@ import numpy as np
 from oracle import orc
 from moonrtx_amd.renderer import MoonRT
 
-EXTRA_KEYS = ("dem_fetches", "mip_fetches", "kernel_ms", "primary_ms", "paths_ms")
+EXTRA_KEYS = ("dem_fetches", "mip_fetches", "kernel_ms", "primary_ms", "paths_ms", "launches")
 STAT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches",
              "background_fetches", "bounce_rays", "bounce_sun_hits")
 

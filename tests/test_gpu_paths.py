@@ -88,3 +88,19 @@ def test_path_queue_with_overlay_tubes(native_lib, rough):
     pos, edges, r, c = overlays.graticule(rotation=s.rotation, tube=0.02)
     caps = overlays.graph_to_capsules(pos, edges, r, c)
     three_way(s, rough, capsules=caps)
+
+
+def test_hand_over_buffers_are_bounded_by_rendering_in_sub_parts(native_lib, rough, monkeypatch):
+    """A frame whose hand-over records would exceed the budget (MOONRT_PATH_MAX_GB; 24 GB by default, e.g. a cfg4 frame with
+    every pixel on the Moon needs 129 GB) is rendered in sub-parts of its tile list through the same buffers -- same frame."""
+    s = named_scene("S1", 160, 128, spp_per_launch=64)
+    s.path_seg_min, s.path_seg_max = 2, 4
+    s.vfov_deg = 2.0                                     # every tile on the Moon: 20 tiles x 1024 wave-jobs
+    lin_o, hits_o, st_o = render_oracle(s, rough)
+    monkeypatch.setenv("MOONRT_PATH_MAX_GB", "0.001")    # -> 4096 wave-jobs per sub-part: five sub-parts
+    for count in (_lib.F_COUNT_STATS, 0):
+        lin, hits, st, _ = render_hip(s, rough, flags=count)
+        assert_bit_equal(lin, lin_o, "sub-parts radiance"); assert_bit_equal(hits, hits_o, "sub-parts hits")
+        if count:
+            assert {k: st[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
+        assert st["launches"] >= 3 * 4
