@@ -315,8 +315,10 @@ def main():
             dom = max(kernels, key=lambda k: kernels[k]["ms"])
             dom_bytes, dom_ms = kernels[dom]["algorithmic_bytes"], kernels[dom]["ms"]
         else:
-            mode = 1 if seg[1] > 1 else 0
-            dom = "render_kernel<%d, false, %s, %d, false>" % (S, wide, mode)
+            if queue:
+                dom = "render_kernel<%d, false, %s, 2, false> + path_kernel<false, %s> + resolve_paths_kernel<%d> (the frame's kernels together)" % (S, wide, wide, S)
+            else:
+                dom = "render_kernel<%d, false, %s, %d, false>" % (S, wide, 1 if seg[1] > 1 else 0)
             dom_bytes, dom_ms = frame_bytes, kernel_ms
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         # PMC evidence comes from SEPARATE rocprofv3 passes of this same command (tools/profile_bench.sh): accepted only
