@@ -29,6 +29,7 @@ print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in eph._asdict()
 W, H = a.size
 scene = ephemeris.scene_from_ephemeris(eph, W, H, spp_per_launch=min(64, a.spp))
 scene.max_spp = a.spp
+scene.path_seg_min, scene.path_seg_max = 2, 4     # what MoonRenderer.init_renderer sets (moon_renderer.py:583)
 if a.elevation_file:
     from moonrtx_amd.ingest import load_elevation_data
     dem, _ = load_elevation_data(a.elevation_file, a.downscale, device=0)     # host float32 (h, w), as the reference returns it
