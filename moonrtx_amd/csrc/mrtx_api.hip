@@ -59,7 +59,7 @@ struct mrtx_ctx {
     uint64_t path_budget_bytes = 24ull << 30;   // hand-over buffers: frames that need more are rendered in sub-parts (MOONRT_PATH_MAX_GB)
     int path_nsub = 4, path_grp_log2 = 3;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
-    int path_refill = 32, path_segmin = 16, path_hitmin = 16, path_policy = 0, path_waves_env = 0;   // cfg3 sweep: (8,24,16) 16.2 ms, (24,24,16) 14.7, (32,16,16) 14.5, (48,24,16) 21.5
+    int path_refill = 32, path_segmin = 16, path_hitmin = 16, path_waves_env = 0;   // cfg3 sweep: (8,24,16) 16.2 ms, (24,24,16) 14.7, (32,16,16) 14.5, (48,24,16) 21.5
     float* accum = nullptr;
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
@@ -447,7 +447,6 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
         if ((e = std::getenv("MOONRT_PATH_NSUB")) && std::atoi(e) >= 1 && std::atoi(e) <= 16) c->path_nsub = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_GRP")) && std::atoi(e) >= 0 && std::atoi(e) <= 10) c->path_grp_log2 = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_MAX_GB")) && std::atof(e) > 0.0) c->path_budget_bytes = (uint64_t)(std::atof(e) * 1073741824.0);
-        if ((e = std::getenv("MOONRT_PATH_POLICY"))) c->path_policy = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_WAVES")) && std::atoi(e) >= 8) c->path_waves_env = std::atoi(e) / 8 * 8;
     }
     c->tiles_x = (cfg->width + c->cfg.tile_w - 1) / c->cfg.tile_w;
@@ -858,7 +857,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             pq.s_log2 = 0;
             while ((1 << pq.s_log2) < S) pq.s_log2++;
             { const int P = 64 / S; const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1; pq.pw_log2 = PW == 8 ? 3 : PW == 4 ? 2 : PW == 2 ? 1 : 0; }
-            pq.refill_min = c->path_refill; pq.seg_min = c->path_segmin; pq.rare_min = c->path_hitmin; pq.policy = c->path_policy;
+            pq.refill_min = c->path_refill; pq.seg_min = c->path_segmin; pq.rare_min = c->path_hitmin;
         }
         const int wi = (stats ? 2 : 0) + (f.dem_wide ? 1 : 0);
         if (c->path_waves[wi] == 0) {

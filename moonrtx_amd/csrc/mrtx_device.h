@@ -133,9 +133,7 @@ struct PathQ {
     int32_t s_log2, pw_log2;    // S = 1 << s_log2 samples per pixel in a wave, pixel block PW x PH, PW = 1 << pw_log2
     int32_t refill_min;         // path_kernel refills its idle lanes when at least this many are idle
     int32_t seg_min;            // ... sets up march segments when at least this many lanes need one
-    int32_t policy;             // 0: thresholds below, 1: greedy (run only the block most lanes wait for; *_min are score biases)
     int32_t rare_min;           // ... and runs the rare steps (a continuation ray hit terrain; a vertex got its direct
                                 //     term) when at least this many lanes wait for them
 };
 #define MRTX_PATH_REC_BYTES 61  // per record: 3 x float4 + 3 x float + 1 byte
-#define MRTX_NO_PATH 1.0e30f

@@ -1236,21 +1236,19 @@ render_kernel(const FrameC f, const PathQ pq) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// D6 behind a queue: everything after the first vertex of a path (set_uint("path_seg_range", 2, 4),
+// D6 behind a queue: what is left of a path after render_kernel<MODE 2> (set_uint("path_seg_range", 2, 4),
 // moon_renderer.py:583).
 //
-// Why not inside render_kernel: a continuation ray is cosine-distributed about the normal and leaves the shell after
-// ~11/sin(elevation) steps -- mean 1.4 segments, but the longest of the 64 rays of a pixel needs 9-10 -- and the
-// few paths that hit terrain again (~8 %) drag the wave through bisection, vertex, shadow march and the next bounce at
-// that lane occupancy.  Here a wave is PERSISTENT and keeps 64 marches in flight whatever path they belong to: every
-// lane is a little state machine, a lane whose path is finished takes the next record of the wave's share of the
-// queue -- a ray that is ready to march: render_kernel has already decided to continue, built the ray and located its
-// origin on the DEM grid while the 64 samples of the pixel were still together --, and the rare heavy steps (a
-// continuation ray that hit terrain: bisection + vertex + light sample; a vertex that got its direct term: roulette +
-// next ray) wait until enough lanes need them.  Shadow and continuation rays share the one segment loop.  No workgroup
-// barrier, no atomics on the data path: wave w of NW owns chunks w, w + NW, ... of the render launch (NW is a
-// multiple of 8, so the chunks a wave reads were written by render_kernel blocks of its own XCD, and the waves of
-// an XCD walk neighbouring pixels of one tile at a time).
+// Why not inside render_kernel: a continuation ray is cosine-distributed about the normal; the 64 rays of a pixel need
+// between one and ten segments, and the few paths that hit terrain again (~8 %) drag the wave through bisection, vertex,
+// shadow march and the next bounce at that lane occupancy (round 1: 35.4 ms against 13.5 ms for direct light).
+// render_kernel<MODE 2> therefore only does what is still coherent -- roulette, the continuation ray, its FIRST segment,
+// which ends 84 % of the paths -- and hands the surviving rays over, compacted per chunk.  Here a wave is PERSISTENT and
+// keeps 64 marches in flight whatever path they belong to: every lane is a little state machine, a lane whose path is
+// finished takes the next record of its wave's current group, and the rare heavy steps (a continuation ray that hit
+// terrain: bisection + vertex + light sample; a vertex that got its direct term: roulette + next ray) wait until enough
+// lanes need them.  Shadow and continuation rays share the one march.  No workgroup barrier; the only atomics hand out
+// groups of chunks (see the kernel body); a watchdog instead of a hang.
 // Every arithmetic step is the one trace_sample<MODE 1> performs for the same (pixel, sample), in the same order, so
 // the three implementations (this, the in-wave loop, the oracle) agree bit for bit.
 #ifndef MRTX_PATH_WAVES
@@ -1258,9 +1256,6 @@ render_kernel(const FrameC f, const PathQ pq) {
 #endif
 #ifndef MRTX_PATH_STEPS
 #define MRTX_PATH_STEPS 2
-#endif
-#ifndef MRTX_PATH_BATCH
-#define MRTX_PATH_BATCH MRTX_STEP_BATCH_BOUNCE
 #endif
 #ifdef MRTX_PATH_PROF   // measurement build only (tools/path_prof.py): block executions and lane counts of path_kernel
 __device__ unsigned long long g_pprof[16];
@@ -1338,21 +1333,12 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         }
         const int n_seg = __popcll(__ballot(state == PS_NEEDSEG)), n_step = __popcll(__ballot(state == PS_STEP));
         const int n_rare = __popcll(__ballot(state == PS_HITWAIT || state == PS_SHADE));
-        bool do_refill, do_seg, do_step, do_rare;
-        if (pq.policy == 0) {
-            do_step = n_step > 0;
-            do_seg = n_seg > 0 && (n_seg >= pq.seg_min || n_step == 0);
-            do_refill = can_refill && nidle > 0 && (nidle >= pq.refill_min || (n_step == 0 && !do_seg));
-            do_rare = n_rare > 0 && (n_rare >= pq.rare_min || (n_step == 0 && !do_seg && !do_refill));
-        } else {   // greedy: only the block most lanes wait for
-            const int sc_refill = can_refill && nidle > 0 ? nidle + pq.refill_min : -1000, sc_seg = n_seg > 0 ? n_seg + pq.seg_min : -1000;
-            const int sc_step = n_step > 0 ? n_step : -1000, sc_rare = n_rare > 0 ? n_rare + pq.rare_min : -1000;
-            const int best = max(max(sc_refill, sc_seg), max(sc_step, sc_rare));
-            do_step = sc_step == best;
-            do_seg = !do_step && sc_seg == best;
-            do_refill = !do_step && !do_seg && sc_refill == best;
-            do_rare = !do_step && !do_seg && !do_refill && sc_rare == best;
-        }
+        // stepping is cheap and runs whenever a lane can step; the others wait for their thresholds, or until nothing cheaper
+        // can make progress.  (Running only the block most lanes wait for was measured: more iterations, 18.9 ms against 17.7.)
+        const bool do_step = n_step > 0;
+        const bool do_seg = n_seg > 0 && (n_seg >= pq.seg_min || n_step == 0);
+        const bool do_refill = can_refill && nidle > 0 && (nidle >= pq.refill_min || (n_step == 0 && !do_seg));
+        const bool do_rare = n_rare > 0 && (n_rare >= pq.rare_min || (n_step == 0 && !do_seg && !do_refill));
 #ifdef MRTX_PATH_PROF
         pf[0]++;
         if (do_refill) { pf[1]++; pf[2] += (uint32_t)nidle; }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Block statistics of path_kernel (a -DMRTX_PATH_PROF build): MOONRT_LIB=ab/libmoonrt_pprof.so python tools/path_prof.py [settings]
-a setting is policy,refill,segmin,raremin."""
+a setting is refill,segmin,raremin."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from bench import WORKLOADS
@@ -15,14 +15,14 @@ scene = named_scene("S1", W, H, spp_per_launch=64); scene.path_seg_min, scene.pa
 lib = _lib.load()
 fn = lib.mrtx_pprof_read; fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 out = (C.c_ulonglong * 16)()
-settings = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(0, 8, 24, 16)]
-for (pol, refill, segmin, rare) in settings:
-    os.environ.update(MOONRT_PATH_POLICY=str(pol), MOONRT_PATH_REFILL=str(refill), MOONRT_PATH_SEGMIN=str(segmin), MOONRT_PATH_HITMIN=str(rare))
+settings = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(32, 16, 16)]
+for (refill, segmin, rare) in settings:
+    os.environ.update(MOONRT_PATH_REFILL=str(refill), MOONRT_PATH_SEGMIN=str(segmin), MOONRT_PATH_HITMIN=str(rare))
     rt = MoonRT(W, H); rt.bind_dem(dem, dem_h, dem_w); rt.bind_color(col, *col_shape); rt.apply_scene(scene); rt.set_params(flags=int(os.environ.get("FLAGS", "0")))
     rt.render(1); fn(out, 1)
     rt.reset(); st = rt.render(1); fn(out, 1)
     v = list(out)
-    print(f"policy {pol} refill {refill} seg {segmin} rare {rare}: paths {st['paths_ms']:.2f} ms; iterations/wave {v[0]/5120:.0f}")
+    print(f"refill {refill} seg {segmin} rare {rare}: paths {st['paths_ms']:.2f} ms; iterations/wave {v[0]/5120:.0f}")
     for i, n in enumerate(("refill", "set-up", "step", "rare")):
         ex, ln = v[1 + 2 * i], v[2 + 2 * i]
         print(f"    {n:7s} executions {ex:12d} ({ex / max(1, v[0]):.2f} per iteration)  lanes waiting {ln / max(1, ex):5.1f}")
