@@ -56,6 +56,7 @@ struct mrtx_ctx {
     // hand-over records of the deferred path stage (PathQ): 6 float arrays of 64 x chunks + one word per chunk
     float* path_rec = nullptr; uint32_t* path_meta = nullptr; uint8_t* path_npaths = nullptr; uint64_t path_cap = 0;
     uint32_t* path_ctr = nullptr;        // 8 x 16 work counters of path_kernel
+    unsigned long long* wd_host = nullptr;   // pinned: path_kernel's watchdog word
     uint64_t path_budget_bytes = 24ull << 30;   // hand-over buffers: frames that need more are rendered in sub-parts (MOONRT_PATH_MAX_GB)
     int path_nsub = 4, path_grp_log2 = 3;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
@@ -493,6 +494,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->path_meta) (void)hipFree(c->path_meta);
     if (c->path_npaths) (void)hipFree(c->path_npaths);
     if (c->path_ctr) (void)hipFree(c->path_ctr);
+    if (c->wd_host) (void)hipHostFree(c->wd_host);
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
@@ -886,10 +888,13 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
                 HIPCHK(c, hipEventRecord(ev[2], c->stream));
             }
         }
+        // path_kernel's watchdog (stats[15]): a wave gave up after 2^24 iterations -- the frame is incomplete.  Read through
+        // pinned memory on the stream, so that the one synchronisation below covers it (no second blocking copy per call).
+        if (!c->wd_host) HIPCHK(c, hipHostMalloc((void**)&c->wd_host, sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(c, hipMemcpyAsync(c->wd_host, c->stats_dev + 15, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        {   // path_kernel's watchdog (stats[15]): a wave gave up after 2^24 iterations -- the frame is incomplete
-            unsigned long long wd = 0;
-            HIPCHK(c, hipMemcpy(&wd, c->stats_dev + 15, sizeof wd, hipMemcpyDeviceToHost));
+        {
+            const unsigned long long wd = *c->wd_host;
             if (wd != 0) {
                 HIPCHK(c, hipMemset(c->stats_dev + 15, 0, sizeof wd));
                 return fail(c, MRTX_E_DEVICE, "path_kernel watchdog: %llu wave(s) did not finish their paths", wd);
