@@ -810,10 +810,11 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         primary_ms = ms;
         launches = 1;
     } else {
-        // The hand-over buffers are sized for the worst case (61 bytes for each of the 64 lanes of every wave-job of the
+        // The hand-over buffers are sized for the worst case (64 bytes for each of the 64 lanes of every wave-job of the
         // launch: 12 GB for the whole-disc cfg3 frame, 129 GB for a cfg4 frame whose every pixel is on the Moon).  A frame
         // that needs more than path_budget_bytes is rendered in SUB-PARTS of its tile list, one after the other through the
         // same buffers: render(sub) -> paths(sub) -> resolve(sub); sub-parts cover disjoint pixels.
+        if (f.kmax >= (1 << 24)) return fail(c, MRTX_E_INVALID, "marching_step too small for deferred paths (%d steps per ray; the hand-over record holds 24 bits)", f.kmax);
         const uint64_t cap_chunks = std::max<uint64_t>(4096, c->path_budget_bytes / (64ull * MRTX_PATH_REC_BYTES));
         int n_sub = 1;
         {
@@ -851,7 +852,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             PathQ& pq = pqs[(size_t)s];
             pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
             pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n;
-            pq.lane_of = reinterpret_cast<uint8_t*>(pq.c2 + n);
+            pq.lane_of = reinterpret_cast<uint32_t*>(pq.c2 + n);
             pq.npaths = c->path_npaths;
             pq.meta = c->path_meta;
             pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;

@@ -112,7 +112,11 @@ struct FrameC {
 // path_kernel (everything after), one RECORD per lane of every wave-job ("chunk") of the render launch:
 //   ray0/1/2  float4 each, only for the samples whose path goes on, compacted to the front of the chunk (npaths[chunk] of
 //             them, lane_of[] says whose): continuation-ray origin (3), direction (3), path throughput (3), exact DEM texel
-//             coordinates of the origin (2), RNG key of the sample (1)
+//             coordinates (2) of the point the march goes on from, RNG key of the sample (1)
+//   lane_of   bits 0-5 the lane (sample) of the chunk the record belongs to, and what render_kernel's trial segment found
+//             out about the ray: bit 6 = still marching after segment 1 (bits 8-31 = its horizon bound kend, the texel
+//             coordinates are those of the END of segment 1), bit 7 = hit inside segment 1 (bits 8-31 = the step k that
+//             landed at/below the surface, the coordinates are the origin's); neither = march from the origin
 //   c0/1/2    the sample's radiance so far (direct term / Sun disk / environment / overlay colour); path_kernel writes
 //             the final value back when the path adds light, resolve_paths_kernel sums the 64 lanes in the butterfly
 //             order of the spec
@@ -121,7 +125,7 @@ struct FrameC {
 struct PathQ {
     float4* ray0; float4* ray1; float4* ray2;
     float* c0; float* c1; float* c2;
-    uint8_t* lane_of;           // per ray record: the lane (sample) of its chunk it belongs to
+    uint32_t* lane_of;          // per ray record: lane + the state of its march after the trial segment (see above)
     uint8_t* npaths;            // per chunk: ray records it holds (0 for a chunk that was not deferred): zero before the launch
     uint32_t* meta;
     uint32_t n_chunks;          // wave-jobs of the render launch (grid x jobs per wave)
@@ -136,4 +140,6 @@ struct PathQ {
     int32_t rare_min;           // ... and runs the rare steps (a continuation ray hit terrain; a vertex got its direct
                                 //     term) when at least this many lanes wait for them
 };
-#define MRTX_PATH_REC_BYTES 61  // per record: 3 x float4 + 3 x float + 1 byte
+#define MRTX_PATH_REC_BYTES 64  // per record: 3 x float4 + 3 x float + 1 word
+#define MRTX_REC_RESUME 64u
+#define MRTX_REC_HIT 128u

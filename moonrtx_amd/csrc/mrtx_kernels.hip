@@ -838,7 +838,7 @@ struct SampleOut {
     // DEFER: the continuation ray of the path (origin, direction, throughput, exact texel coordinates of the origin)
     // and the sample's RNG key, for path_kernel
     float oa, ob, oc, da, db, dc, t0, t1, t2, row, col;
-    uint32_t ks;
+    uint32_t ks, aux;   // aux: MRTX_REC_RESUME | kend << 8, MRTX_REC_HIT | k << 8, or 0 (PathQ::lane_of)
     bool path;
 };
 
@@ -1005,14 +1005,14 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 float q2;
                 exact_rowcol(f, o.oa, o.ob, o.oc, o.row, o.col, q2);
                 o.t0 = t0r; o.t1 = t1r; o.t2 = t2r;
-                o.ks = ks;
+                o.ks = ks; o.aux = 0u;
                 if (STATS) cnt[ST_BOUNCE]++;
 #if MRTX_TRIAL_SEGMENT
                 // The FIRST segment of the continuation ray is marched right here: the 64 rays of the pixel still start
                 // within a texel of each other, every lane is busy, and four rays in five end inside it without touching
                 // the terrain again (they have cleared everything in reach, horizon_kend, or left the shell) -- those paths
-                // are finished in this wave.  A ray that hits, or is still marching after 16 steps, goes to path_kernel,
-                // which marches it from its origin (so its evaluations are counted there, not here).
+                // are finished in this wave.  A ray that hits, or is still marching after 16 steps, goes to path_kernel WITH
+                // what the segment found out: the step that landed below the surface, or the state at the segment's end.
                 uint32_t tcnt[ST_N];
                 if (STATS) {
 #pragma unroll
@@ -1024,14 +1024,20 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 Seg tsg;
                 float tsk = 0.0f;
                 if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
+                if (STATS) {
+#pragma unroll
+                    for (int i = 0; i < ST_N; i++) cnt[i] += tcnt[i];
+                }
                 if (!tgo && !thit) {
                     escaped_path<STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, t0r, t1r, t2r, o.c0, o.c1, o.c2, cnt);
-                    if (STATS) {
-#pragma unroll
-                        for (int i = 0; i < ST_N; i++) cnt[i] += tcnt[i];
-                    }
                 } else {
                     o.path = true;
+                    if (thit) {
+                        o.aux = MRTX_REC_HIT | ((uint32_t)(int)rintf(tsk * f.inv_step) << 8);
+                    } else {
+                        o.aux = MRTX_REC_RESUME | ((uint32_t)tm.kend << 8);
+                        o.row = tm.rowA; o.col = tm.colA;
+                    }
                 }
 #else
                 o.path = true;
@@ -1172,7 +1178,7 @@ render_kernel(const FrameC f, const PathQ pq) {
         SampleOut o;
         o.h0 = o.h1 = o.h2 = o.h3 = 0.f;
         o.path = false;
-        o.oa = o.ob = o.oc = o.da = o.db = o.dc = o.t0 = o.t1 = o.t2 = o.row = o.col = 0.f; o.ks = 0u;
+        o.oa = o.ob = o.oc = o.da = o.db = o.dc = o.t0 = o.t1 = o.t2 = o.row = o.col = 0.f; o.ks = 0u; o.aux = 0u;
         bool deferred = false;
         for (uint32_t blk = 0; blk < f.n_blocks; blk++) {   // DEFER launches carry one block each
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
@@ -1194,7 +1200,7 @@ render_kernel(const FrameC f, const PathQ pq) {
                     nt_store4(pq.ray0 + es, o.oa, o.ob, o.oc, o.da);
                     nt_store4(pq.ray1 + es, o.db, o.dc, o.t0, o.t1);
                     nt_store4(pq.ray2 + es, o.t2, o.row, o.col, __uint_as_float(o.ks));
-                    pq.lane_of[es] = (uint8_t)lane;
+                    pq.lane_of[es] = (uint32_t)lane | o.aux;
                 }
                 __builtin_nontemporal_store(o.c0, pq.c0 + e);
                 __builtin_nontemporal_store(o.c1, pq.c1 + e);
@@ -1384,8 +1390,29 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             }
             if (fill_l) {
                 const float4 r0 = nt_load4(pq.ray0 + e), r1 = nt_load4(pq.ray1 + e), r2 = nt_load4(pq.ray2 + e);
+                const uint32_t aux = __builtin_nontemporal_load(pq.lane_of + e);
+                e = (e & ~63u) | (aux & 63u);            // from here on: the sample's slot in c0/c1/c2
                 m.rowA = r2.y; m.colA = r2.z;
-                const bool go = march_begin_at<false, STATS>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
+                bool go = true;
+                j = 1;
+                if (aux & MRTX_REC_RESUME) {
+                    // render_kernel marched segment 1 and the ray is still going: take the march up at step 16 (the record
+                    // carries the texel coordinates there and the horizon bound; the rest follows from the ray)
+                    m.oa = r0.x; m.ob = r0.y; m.oc = r0.z; m.da = r0.w; m.db = r1.x; m.dc = r1.y;
+                    m.rq.q0 = fmaf(m.oc, m.oc, fmaf(m.ob, m.ob, m.oa * m.oa));
+                    m.rq.b = fmaf(m.oc, m.dc, fmaf(m.ob, m.db, m.oa * m.da));
+                    m.rq.a = fmaf(m.dc, m.dc, fmaf(m.db, m.db, m.da * m.da));
+                    const float sb = (float)SEG_N * f.step;
+                    const float pa = fmaf(sb, m.da, m.oa), pb = fmaf(sb, m.db, m.ob);
+                    m.q2A = fmaf(pb, pb, pa * pa);
+                    m.ka = SEG_N;
+                    m.kend = (int)(aux >> 8);
+                } else {
+                    go = march_begin_at<false, STATS>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
+                    // ... or found the step that lands below the surface: only the segment's quadratic is needed again
+                    // (for the bisection); j < 0 tells the set-up block
+                    if (aux & MRTX_REC_HIT) { go = true; j = -(int)(aux >> 8); }
+                }
                 t0r = r1.z; t1r = r1.w; t2r = r2.x;
                 ks = __float_as_uint(r2.w);
                 hit = false; shadow = false; have_c = false;
@@ -1397,12 +1424,21 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             // ---- segment set-up for the lanes that need one
             if (state == PS_NEEDSEG) {
                 float rowB, colB, q2B;
+                const int known_hit = j;                    // < 0: render_kernel stepped this segment already, the hit is at step -j
+                const uint32_t mip0 = STATS ? cnt[ST_MIP] : 0u;
                 seg_setup<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, m.rq, m.ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
-                if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, 1, sg.jlo - 1);
-                m.rowA = rowB; m.colA = colB; m.q2A = q2B;   // the next segment starts where this one ends
-                sg.jhi = max(min(sg.jhi, m.kend - m.ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
-                j = sg.jlo;
-                if (j <= sg.jhi) state = PS_STEP; else segend = true;
+                if (known_hit < 0) {
+                    if (STATS) cnt[ST_MIP] = mip0;          // counted where the segment was marched
+                    hit = true; sk_hit = (float)(-known_hit) * f.step;
+                    j = 1;
+                    state = PS_ENDED;
+                } else {
+                    if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, 1, sg.jlo - 1);
+                    m.rowA = rowB; m.colA = colB; m.q2A = q2B;   // the next segment starts where this one ends
+                    sg.jhi = max(min(sg.jhi, m.kend - m.ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
+                    j = sg.jlo;
+                    if (j <= sg.jhi) state = PS_STEP; else segend = true;
+                }
             }
         }
         if (do_step) {
@@ -1463,7 +1499,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 // the path left the Moon: Sun disk / environment along the ray, if there is any
                 float e0, e1, e2;
                 if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {
-                    if (!have_c) { e = (e & ~63u) | (uint32_t)pq.lane_of[e]; c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                    if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
                     c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
                 }
                 if (have_c) { pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2; }
@@ -1476,7 +1512,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         // continued or ended (~250 VALU).  They wait until enough lanes need them -- or nothing is marching.
         if (do_rare) {
             if (state == PS_HITWAIT) {
-                if (!have_c) { e = (e & ~63u) | (uint32_t)pq.lane_of[e]; c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
                 const int bk = (int)rintf(sk_hit * f.inv_step);
                 float blo = (float)(bk - 1) * f.step, bhi = sk_hit;
                 refine<WIDE>(f, sg, m.oa, m.ob, m.oc, m.da, m.db, m.dc, blo, bhi);

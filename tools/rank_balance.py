@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-rank kernel time of the sharded cfg3 frame, measured one rank after another on ONE GPU: the load balance of the
+"""Per-rank kernel time of the sharded cfg3 frame (PATH_SEG=2,4 by default; 1,1 = direct light), measured one rank after another on ONE GPU: the load balance of the
 tile deal (tile t -> rank t % world) and the bytes each rank would send.  python tools/rank_balance.py [world ...]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -13,8 +13,9 @@ dem_buf, _ = dem_from_ldem(src, dem_h, dem_w, 1, device=0)
 src.free()
 col = synth_color(col_shape[0], col_shape[1], device=0)
 scene = named_scene(os.environ.get("SCENE", "S1"), W, H, spp_per_launch=64)
+scene.path_seg_min, scene.path_seg_max = (int(t) for t in os.environ.get("PATH_SEG", "2,4").split(","))
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
-    ms, nbytes = [], 0
+    ms, nbytes, split = [], 0, []
     for r in range(world):
         rt = MoonRT(W, H, device=0, rank=r, world=world)
         rt.bind_dem(dem_buf, dem_h, dem_w)
@@ -24,10 +25,11 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         rt.reset(); rt.render(1)
         t = []
         for _ in range(3):
-            rt.reset(); t.append(rt.render(1)["kernel_ms"])
-        ms.append(min(t))
+            rt.reset(); st = rt.render(1); t.append((st["kernel_ms"], st["primary_ms"], st["paths_ms"]))
+        ms.append(min(t)[0]); split.append(min(t)[1:])
         nbytes = rt.shard_bytes_active() if world > 1 else 0
         full = rt.shard_bytes()
         rt.close()
     print(f"world {world}: kernel ms per rank min {min(ms):.3f} mean {sum(ms) / len(ms):.3f} max {max(ms):.3f} "
-          f"(imbalance {max(ms) / (sum(ms) / len(ms)) - 1:.1%}); sum {sum(ms):.2f}; shard {nbytes / 1e6:.1f} MB active of {full / 1e6:.1f} MB")
+          f"(imbalance {max(ms) / (sum(ms) / len(ms)) - 1:.1%}); sum {sum(ms):.2f}; shard {nbytes / 1e6:.1f} MB active of {full / 1e6:.1f} MB; "
+          f"slowest rank: render {max(split)[0]:.3f} + paths {max(split)[1]:.3f}")
