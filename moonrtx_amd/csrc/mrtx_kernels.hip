@@ -1266,7 +1266,7 @@ render_kernel(const FrameC f, const PathQ pq) {
 #ifdef MRTX_PATH_PROF   // measurement build only (tools/path_prof.py): block executions and lane counts of path_kernel
 __device__ unsigned long long g_pprof[16];
 #endif
-enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_ENDED, PS_HITWAIT, PS_SHADE };
+enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_BISECT, PS_ENDED, PS_HITWAIT, PS_SHADE };
 
 // The march inside path_kernel is cut at STEP granularity, not at segment granularity: within one 16-step segment
 // the rays of a wave need anything from 0 to 16 dependent DEM fetches (mean ~4), and a wave that steps a whole
@@ -1320,6 +1320,10 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     float sk_hit = 0.0f;
     Vertex v;
     float t0r = 1.0f, t1r = 1.0f, t2r = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, carried = 0.0f, wgt = 0.0f;
+    // BISECT lanes (a continuation ray that hit: D3's bisection, one level per DEM fetch like any other step) keep the
+    // bracket in registers that are dead meanwhile: lo in wgt, hi in sk_hit, the levels left in j
+    float& bis_lo = wgt;
+    float& bis_hi = sk_hit;
     m.oa = m.ob = m.oc = m.da = m.db = m.dc = 0.0f; m.rq.q0 = m.rq.b = m.rq.a = 0.0f; m.rowA = m.colA = m.q2A = 0.0f; m.ka = 0; m.kend = 0;
     sg.sa = sg.ra = sg.r1 = sg.r2 = sg.ca = sg.c1 = sg.c2 = 0.0f; sg.jlo = 1; sg.jhi = 0; sg.exact = false;
     v.pa = v.pb = v.pc = v.na = v.nb = v.nc = v.al0 = v.al1 = v.al2 = 0.0f;
@@ -1337,7 +1341,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             if (lane == 0) atomicAdd(&CF(f)->stats[15], 1ull);
             break;
         }
-        const int n_seg = __popcll(__ballot(state == PS_NEEDSEG)), n_step = __popcll(__ballot(state == PS_STEP));
+        const int n_seg = __popcll(__ballot(state == PS_NEEDSEG)), n_step = __popcll(__ballot(state == PS_STEP || state == PS_BISECT));
         const int n_rare = __popcll(__ballot(state == PS_HITWAIT || state == PS_SHADE));
         // stepping is cheap and runs whenever a lane can step; the others wait for their thresholds, or until nothing cheaper
         // can make progress.  (Running only the block most lanes wait for was measured: more iterations, 18.9 ms against 17.7.)
@@ -1446,20 +1450,37 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             // memory round trip per iteration is what bounds this kernel), then the steps are tested in march order and
             // whatever follows the one that ends the march or the segment is dropped (its fetch is wasted).  Same
             // evaluations, same order, same results as one step at a time.  cfg3: 1 step 14.5 ms, 2 steps 13.3.
-            if (state == PS_STEP) {
+            if (state == PS_STEP || state == PS_BISECT) {
+                // A BISECT lane evaluates the mid-point of its bracket in slot 0 and, speculatively, the mid-point of the
+                // lower half in slot 1 (the next level if slot 0 turns out below the surface): the bisection of D3 rides the
+                // fetch rounds of the march instead of adding five of its own to the rare block.
+                const bool bis = state == PS_BISECT;
                 bool bel[MRTX_PATH_STEPS], in[MRTX_PATH_STEPS];
                 float sks[MRTX_PATH_STEPS];
+                const float mid0 = 0.5f * (bis_lo + bis_hi);
 #pragma unroll
                 for (int i = 0; i < MRTX_PATH_STEPS; i++) {
                     const int k = m.ka + min(j + i, sg.jhi);                 // a step past jhi is read at jhi instead
-                    const float sk = (float)k * f.step;
+                    const float sk = bis ? (i == 1 ? 0.5f * (bis_lo + mid0) : mid0) : (float)k * f.step;
                     const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
                     const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
                     in[i] = (r2 <= f.R2f) & (k <= f.kmax);
                     bel[i] = below_seg<WIDE, true>(f, sg, sk, pa, pb, pc, r2);
                     sks[i] = sk;
                 }
-                bool act = true;
+                bool act = !bis;
+                if (bis) {
+                    bis_hi = bel[0] ? mid0 : bis_hi;
+                    bis_lo = bel[0] ? bis_lo : mid0;
+                    j--;
+                    if (MRTX_PATH_STEPS > 1 && j > 0 && bel[0]) {           // the speculated level was the right one
+                        const float mid1 = sks[1];                          // == 0.5f * (lo + hi) of the new bracket
+                        bis_hi = bel[1] ? mid1 : bis_hi;
+                        bis_lo = bel[1] ? bis_lo : mid1;
+                        j--;
+                    }
+                    if (j <= 0) state = PS_HITWAIT;
+                }
 #pragma unroll
                 for (int i = 0; i < MRTX_PATH_STEPS; i++) {
                     if (act) {
@@ -1494,7 +1515,12 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 wgt = hit ? 0.0f : carried;
                 state = PS_SHADE;
             } else if (hit) {
-                state = PS_HITWAIT;
+                // D3: bracket the crossing between the last step above and the first step at/below the surface
+                const int bk = (int)rintf(sk_hit * f.inv_step);
+                bis_lo = (float)(bk - 1) * f.step;       // bis_hi is sk_hit already
+                j = f.nbis;
+                if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
+                state = f.nbis > 0 ? PS_BISECT : PS_HITWAIT;
             } else {
                 // the path left the Moon: Sun disk / environment along the ray, if there is any
                 float e0, e1, e2;
@@ -1513,10 +1539,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         if (do_rare) {
             if (state == PS_HITWAIT) {
                 if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
-                const int bk = (int)rintf(sk_hit * f.inv_step);
-                float blo = (float)(bk - 1) * f.step, bhi = sk_hit;
-                refine<WIDE>(f, sg, m.oa, m.ob, m.oc, m.da, m.db, m.dc, blo, bhi);
-                if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
+                const float blo = bis_lo;                  // the bisected bracket's upper side (PS_BISECT)
                 hit_vertex<STATS, WIDE>(f, fmaf(blo, m.da, m.oa), fmaf(blo, m.db, m.ob), fmaf(blo, m.dc, m.oc), v, cnt);
                 seg++;
                 const uint32_t d0 = 4u + 5u * (seg - 2u);   // the dimensions drawn when this segment was started
