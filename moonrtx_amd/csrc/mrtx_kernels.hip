@@ -461,7 +461,9 @@ __device__ __forceinline__ uint32_t steps_after(const FrameC& f, const MarchStat
 // Start of a march: exact coordinates at the origin, r^2(s) coefficients; returns `go` (false: the march is over before
 // its first step).
 // ... with the exact texel coordinates of the origin already known (m.rowA, m.colA)
-template <bool PRIMARY, bool STATS>
+// LAZY_KEND (path_kernel): the horizon bound is left open (m.kend = -1) and looked up by the first segment set-up, in the
+// same memory round as that segment's max-mip fetch, instead of costing a round of its own here.
+template <bool PRIMARY, bool STATS, bool LAZY_KEND = false>
 __device__ __forceinline__ bool march_begin_at(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                                MarchState& m, uint32_t* cnt) {
     m.oa = oa; m.ob = ob; m.oc = oc; m.da = da; m.db = db; m.dc = dc;
@@ -478,22 +480,26 @@ __device__ __forceinline__ bool march_begin_at(const FrameC& f, float oa, float 
         const float s1 = f.step;
         const float pa = fmaf(s1, da, oa), pb = fmaf(s1, db, ob), pc = fmaf(s1, dc, oc);
         go = fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f;
-        m.kend = horizon_kend(f, m);
-        if (go && m.kend < 1) {          // already above everything in reach: no step can hit
-            if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, 1);
-            go = false;
+        if (LAZY_KEND) {
+            m.kend = -1;
+        } else {
+            m.kend = horizon_kend(f, m);
+            if (go && m.kend < 1) {          // already above everything in reach: no step can hit
+                if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, 1);
+                go = false;
+            }
         }
     } else {
         m.kend = f.kmax;
     }
     return go;
 }
-template <bool PRIMARY, bool STATS>
+template <bool PRIMARY, bool STATS, bool LAZY_KEND = false>
 __device__ __forceinline__ bool march_begin(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                             MarchState& m, uint32_t* cnt) {
     float q2;
     exact_rowcol(f, oa, ob, oc, m.rowA, m.colA, q2);
-    return march_begin_at<PRIMARY, STATS>(f, oa, ob, oc, da, db, dc, m, cnt);
+    return march_begin_at<PRIMARY, STATS, LAZY_KEND>(f, oa, ob, oc, da, db, dc, m, cnt);
 }
 
 // ONE 16-step segment of a march (the lanes that call it are still marching): anchors + skip interval, the steps
@@ -1355,6 +1361,10 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         if (do_seg) { pf[3]++; pf[4] += (uint32_t)n_seg; }
         if (do_step) { pf[5]++; pf[6] += (uint32_t)n_step; }
         if (do_rare) { pf[7]++; pf[8] += (uint32_t)n_rare; }
+#define PPROF_T(i) { const unsigned long long _t = __builtin_readcyclecounter(); pf[i] += (uint32_t)(_t - pt); pt = _t; }
+        unsigned long long pt = __builtin_readcyclecounter();
+#else
+#define PPROF_T(i)
 #endif
 
         bool segend = false;
@@ -1399,23 +1409,29 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 m.rowA = r2.y; m.colA = r2.z;
                 bool go = true;
                 j = 1;
-                if (aux & MRTX_REC_RESUME) {
-                    // render_kernel marched segment 1 and the ray is still going: take the march up at step 16 (the record
-                    // carries the texel coordinates there and the horizon bound; the rest follows from the ray)
+                if (aux & (MRTX_REC_RESUME | MRTX_REC_HIT)) {
                     m.oa = r0.x; m.ob = r0.y; m.oc = r0.z; m.da = r0.w; m.db = r1.x; m.dc = r1.y;
-                    m.rq.q0 = fmaf(m.oc, m.oc, fmaf(m.ob, m.ob, m.oa * m.oa));
+                    m.q2A = fmaf(m.ob, m.ob, m.oa * m.oa);
+                    m.rq.q0 = fmaf(m.oc, m.oc, m.q2A);
                     m.rq.b = fmaf(m.oc, m.dc, fmaf(m.ob, m.db, m.oa * m.da));
                     m.rq.a = fmaf(m.dc, m.dc, fmaf(m.db, m.db, m.da * m.da));
-                    const float sb = (float)SEG_N * f.step;
-                    const float pa = fmaf(sb, m.da, m.oa), pb = fmaf(sb, m.db, m.ob);
-                    m.q2A = fmaf(pb, pb, pa * pa);
-                    m.ka = SEG_N;
-                    m.kend = (int)(aux >> 8);
+                    if (aux & MRTX_REC_RESUME) {
+                        // render_kernel marched segment 1 and the ray is still going: take the march up at step 16 (the
+                        // record carries the texel coordinates there and the horizon bound; the rest follows from the ray)
+                        const float sb = (float)SEG_N * f.step;
+                        const float pa = fmaf(sb, m.da, m.oa), pb = fmaf(sb, m.db, m.ob);
+                        m.q2A = fmaf(pb, pb, pa * pa);
+                        m.ka = SEG_N;
+                        m.kend = (int)(aux >> 8);
+                    } else {
+                        // ... or found the step that lands below the surface: only the segment's quadratic is needed again
+                        // (for the bisection); j < 0 tells the set-up block
+                        m.ka = 0;
+                        m.kend = f.kmax;
+                        j = -(int)(aux >> 8);
+                    }
                 } else {
-                    go = march_begin_at<false, STATS>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
-                    // ... or found the step that lands below the surface: only the segment's quadratic is needed again
-                    // (for the bisection); j < 0 tells the set-up block
-                    if (aux & MRTX_REC_HIT) { go = true; j = -(int)(aux >> 8); }
+                    go = march_begin_at<false, STATS, true>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
                 }
                 t0r = r1.z; t1r = r1.w; t2r = r2.x;
                 ks = __float_as_uint(r2.w);
@@ -1424,14 +1440,21 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 state = go ? PS_NEEDSEG : PS_ENDED;
             }
         }
+        PPROF_T(9);
         if (do_seg) {
             // ---- segment set-up for the lanes that need one
             if (state == PS_NEEDSEG) {
                 float rowB, colB, q2B;
                 const int known_hit = j;                    // < 0: render_kernel stepped this segment already, the hit is at step -j
                 const uint32_t mip0 = STATS ? cnt[ST_MIP] : 0u;
+                const bool open_kend = m.kend < 0;          // first segment of a march begun in this kernel: the horizon
+                if (open_kend) m.kend = horizon_kend(f, m); // bound is looked up beside the max-mip (one memory round)
                 seg_setup<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, m.rq, m.ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
-                if (known_hit < 0) {
+                if (open_kend && m.kend < 1) {
+                    // already above everything in reach: no step can hit, the march ends before its first segment
+                    if (STATS) { cnt[ST_MIP] = mip0; cnt[ST_HEIGHT] += steps_after(f, m, 1); }
+                    state = PS_ENDED;
+                } else if (known_hit < 0) {
                     if (STATS) cnt[ST_MIP] = mip0;          // counted where the segment was marched
                     hit = true; sk_hit = (float)(-known_hit) * f.step;
                     j = 1;
@@ -1445,6 +1468,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 }
             }
         }
+        PPROF_T(10);
         if (do_step) {
             // ---- the next MRTX_PATH_STEPS steps of every stepping lane: their DEM footprints are fetched together (one
             // memory round trip per iteration is what bounds this kernel), then the steps are tested in march order and
@@ -1494,6 +1518,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             }
         }
 
+        PPROF_T(11);
         // ---- end of a segment that is neither hit nor left: did the ray end inside the skipped tail?
         if (segend) {
             if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, max(sg.jhi + 1, 1), SEG_N);
@@ -1515,7 +1540,9 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 wgt = hit ? 0.0f : carried;
                 state = PS_SHADE;
             } else if (hit) {
-                // D3: bracket the crossing between the last step above and the first step at/below the surface
+                // D3: bracket the crossing between the last step above and the first step at/below the surface; the sample's
+                // radiance so far is fetched now, to arrive while the bisection runs
+                if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
                 const int bk = (int)rintf(sk_hit * f.inv_step);
                 bis_lo = (float)(bk - 1) * f.step;       // bis_hi is sk_hit already
                 j = f.nbis;
@@ -1536,9 +1563,9 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         // ---- the rare steps (~8 % of the paths reach them): a continuation ray that hit terrain gets its vertex and
         // light sample (~600 VALU); a vertex whose shadow ray is through gets its direct term, and the path is
         // continued or ended (~250 VALU).  They wait until enough lanes need them -- or nothing is marching.
+        PPROF_T(12);
         if (do_rare) {
             if (state == PS_HITWAIT) {
-                if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
                 const float blo = bis_lo;                  // the bisected bracket's upper side (PS_BISECT)
                 hit_vertex<STATS, WIDE>(f, fmaf(blo, m.da, m.oa), fmaf(blo, m.db, m.ob), fmaf(blo, m.dc, m.oc), v, cnt);
                 seg++;
@@ -1547,7 +1574,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 float soa, sob, soc, swa, swb, swc;
                 if (light_sample(f, v, ul1, ul2, soa, sob, soc, swa, swb, swc, carried)) {
                     if (STATS) cnt[ST_SHADOW]++;
-                    const bool go = march_begin<false, STATS>(f, soa, sob, soc, swa, swb, swc, m, cnt);
+                    const bool go = march_begin<false, STATS, true>(f, soa, sob, soc, swa, swb, swc, m, cnt);
                     hit = false; shadow = true;
                     state = go ? PS_NEEDSEG : PS_ENDED;
                 } else {
@@ -1562,7 +1589,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 float boa, bob, boc, bda, bdb, bdc;
                 if (continue_path(f, v, ks, seg, t0r, t1r, t2r, boa, bob, boc, bda, bdb, bdc)) {
                     if (STATS) cnt[ST_BOUNCE]++;
-                    const bool go = march_begin<false, STATS>(f, boa, bob, boc, bda, bdb, bdc, m, cnt);
+                    const bool go = march_begin<false, STATS, true>(f, boa, bob, boc, bda, bdb, bdc, m, cnt);
                     hit = false; shadow = false;
                     state = go ? PS_NEEDSEG : PS_ENDED;
                 } else {
@@ -1571,6 +1598,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 }
             }
         }
+        PPROF_T(13);
     }
 
 #ifdef MRTX_PATH_PROF

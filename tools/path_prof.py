@@ -26,4 +26,8 @@ for (refill, segmin, rare) in settings:
     for i, n in enumerate(("refill", "set-up", "step", "rare")):
         ex, ln = v[1 + 2 * i], v[2 + 2 * i]
         print(f"    {n:7s} executions {ex:12d} ({ex / max(1, v[0]):.2f} per iteration)  lanes waiting {ln / max(1, ex):5.1f}")
+    tot = sum(v[9:14])
+    if tot:
+        names = ("bookkeeping + refill", "set-up", "step", "segment end + march over", "rare")
+        print("    wave cycles: " + ", ".join(f"{n} {v[9 + i] / tot:.3f} ({v[9 + i] / max(1, v[(1, 3, 5, 0, 7)[i]]):.0f}/exec)" for i, n in enumerate(names)) + f"; {tot / 5120 / 1e6:.2f} M cycles per wave")
     rt.close()
