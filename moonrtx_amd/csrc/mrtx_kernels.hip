@@ -1622,21 +1622,46 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
 // spec (block sum), then onto the running sum -- exactly what render_kernel does in registers.
 template <int S>
 __global__ void __launch_bounds__(256) resolve_paths_kernel(const FrameC f, const PathQ pq) {
+    // A wave takes U consecutive chunks at a time: their meta words in one round, then every load of the deferred ones (sample
+    // values and running sums) in a second -- the kernel is a pure stream, bound by the bytes it keeps in flight.
+    constexpr uint32_t U = 4;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    for (uint32_t chunk = blockIdx.x * 4u + wv; chunk < pq.n_chunks; chunk += gridDim.x * 4u) {
-        const uint32_t mt = pq.meta[chunk];
-        if (!(mt & 0x80000000u)) continue;
-        const uint32_t e = chunk * 64u + lane;
-        const float t0 = tree_sum<S>(__builtin_nontemporal_load(pq.c0 + e)), t1 = tree_sum<S>(__builtin_nontemporal_load(pq.c1 + e)),
-                    t2 = tree_sum<S>(__builtin_nontemporal_load(pq.c2 + e));
-        const uint32_t pp = lane >> pq.s_log2, ss = lane & ((1u << pq.s_log2) - 1u);
-        const uint32_t x = (mt & 0x7FFFu) + (pp & ((1u << pq.pw_log2) - 1u));
-        const uint32_t y = ((mt >> 15) & 0x7FFFu) + (pp >> pq.pw_log2);
-        if (ss == 0u && x < (uint32_t)f.W && y < (uint32_t)f.H) {
-            float4* a = reinterpret_cast<float4*>(CF(f)->accum) + ((int64_t)y * f.W + x);
-            float4 t = *a;
-            t.x += t0; t.y += t1; t.z += t2;
-            *a = t;
+    const uint32_t pp = lane >> pq.s_log2, ss = lane & ((1u << pq.s_log2) - 1u);
+    for (uint32_t base = (blockIdx.x * 4u + wv) * U; base < pq.n_chunks; base += gridDim.x * 4u * U) {
+        uint32_t mt[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) mt[u] = base + u < pq.n_chunks ? pq.meta[base + u] : 0u;
+        float a0[U], a1[U], a2[U];
+        float4 acc[U];
+        float4* ap[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            ap[u] = nullptr;
+            a0[u] = a1[u] = a2[u] = 0.0f;
+            acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mt[u] & 0x80000000u) {                       // wave-uniform
+                const uint32_t e = (base + u) * 64u + lane;
+                a0[u] = __builtin_nontemporal_load(pq.c0 + e);
+                a1[u] = __builtin_nontemporal_load(pq.c1 + e);
+                a2[u] = __builtin_nontemporal_load(pq.c2 + e);
+                const uint32_t x = (mt[u] & 0x7FFFu) + (pp & ((1u << pq.pw_log2) - 1u));
+                const uint32_t y = ((mt[u] >> 15) & 0x7FFFu) + (pp >> pq.pw_log2);
+                if (ss == 0u && x < (uint32_t)f.W && y < (uint32_t)f.H) {
+                    ap[u] = reinterpret_cast<float4*>(CF(f)->accum) + ((int64_t)y * f.W + x);
+                    acc[u] = *ap[u];
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            if (mt[u] & 0x80000000u) {
+                const float t0 = tree_sum<S>(a0[u]), t1 = tree_sum<S>(a1[u]), t2 = tree_sum<S>(a2[u]);
+                if (ap[u]) {
+                    float4 t = acc[u];
+                    t.x += t0; t.y += t1; t.z += t2;
+                    *ap[u] = t;
+                }
+            }
         }
     }
 }
@@ -2079,7 +2104,7 @@ hipError_t mrtx_launch_paths(const FrameC& f, const PathQ& pq, int S, bool stats
            else hipLaunchKernelGGL((mrtx::path_kernel<false, false>), grid, block, 0, st, f, pq); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    unsigned rb = (pq.n_chunks + 3u) / 4u;
+    unsigned rb = (pq.n_chunks + 15u) / 16u;   // 4 waves x 4 chunks per block and turn
     if (rb > 65536u) rb = 65536u;
     const dim3 rgrid(rb), rblock(256);
     switch (S) {
