@@ -523,7 +523,7 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
         step_loop<WIDE, PRIMARY, STATS, false, BATCH>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
     PROF_END(7);
 #ifdef MRTX_PROF
-#ifndef MRTX_PROF_SPREAD
+#if !defined(MRTX_PROF_SPREAD) && !defined(MRTX_PROF_TRIAL)
     cnt[8] += 1;                                     // wave-level segments
     cnt[9] += (uint32_t)__popcll(__ballot(true));    // lanes alive in them
     cnt[PRIMARY ? 13 : 14] += (__ballot(sg.jlo <= sg.jhi) == 0ull) ? 1u : 0u;   // wave-level segments nobody steps in
@@ -1019,7 +1019,13 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 // the terrain again (they have cleared everything in reach, horizon_kend, or left the shell) -- those paths
                 // are finished in this wave.  A ray that hits, or is still marching after 16 steps, goes to path_kernel WITH
                 // what the segment found out: the step that landed below the surface, or the state at the segment's end.
+#ifdef MRTX_PROF
+                uint32_t tcnt[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) tcnt[i] = 0;
+#else
                 uint32_t tcnt[ST_N];
+#endif
                 if (STATS) {
 #pragma unroll
                     for (int i = 0; i < ST_N; i++) tcnt[i] = 0;
@@ -1030,6 +1036,9 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 Seg tsg;
                 float tsk = 0.0f;
                 if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
+#ifdef MRTX_PROF_TRIAL   // measurement only: the trial's step iterations and the lanes evaluating in them (slots 13 / 14), its cycles (15)
+                cnt[13] += tcnt[11]; cnt[14] += tcnt[12]; cnt[15] += tcnt[6] + tcnt[7];
+#endif
                 if (STATS) {
 #pragma unroll
                     for (int i = 0; i < ST_N; i++) cnt[i] += tcnt[i];
