@@ -306,8 +306,8 @@ def main():
                 "ms": round(primary_ms, 3), "algorithmic_bytes": int(a_bytes),
                 "achieved": round(a_bytes / (primary_ms * 1e-3) / 1e9, 1), "frac": round(a_bytes / (primary_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "does": "camera ray, march, first vertex, light sample + shadow march, roulette + continuation ray + its first "
-                        "segment, hand-over records; its algorithmic bytes are those of the direct frame (the trial segment's "
-                        "evaluations are booked with the path stage)"}
+                        "segment, hand-over records; its algorithmic bytes are those of the direct frame -- a lower bound: the "
+                        "evaluations of the trial segment, which this kernel performs as well, are booked with the path stage in this split"}
             p_bytes = frame_bytes - a_bytes
             kernels["path_kernel<false, %s> + resolve_paths_kernel<%d>" % (wide, S)] = {
                 "ms": round(paths_ms, 3), "algorithmic_bytes": int(p_bytes),
