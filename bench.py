@@ -294,7 +294,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         rays = W * H * spp
         wide = "true" if (dem_h + 4) * (dem_w + 4) * 8 > 0xFFFFFFFF else "false"
-        queue = seg[1] > 1 and not args.inwave_paths
+        queue = seg[1] > 1 and not args.inwave_paths and paths_ms > 0.0   # small launches keep their paths in the wave (MOONRT_PATH_QUEUE_MIN)
         # ---- roofline.  Bytes are ALGORITHMIC; time is the HIP-event duration of the kernels.
         px_adj = -32 * W * H + 32 * W * H // world
         frame_bytes = algorithmic_bytes(counted, W, H) + px_adj
@@ -377,8 +377,8 @@ def main():
                                       + (", RCCL gather of float4 radiance+hits to rank 0" if world > 1 else ""),
                        "march": "step 5e-3, eps 3e-4, scene_epsilon 1e-4, 1 light sample + shadow ray per path vertex, "
                                 f"path_seg_range {seg}" + (" (direct light only)" if seg[1] <= 1 else
-                                                          (", paths continued inside the render wave" if args.inwave_paths else
-                                                           ", paths continued by persistent waves behind a record queue"))},
+                                                          (", paths continued by persistent waves behind a record queue" if queue else
+                                                           ", paths continued inside the render wave"))},
             "distributed": {"backend": backend, "world_size": dist_world,
                             "per_rank_[wall_s, kernel_ms, primary_ms, paths_ms]": per_rank,
                             "gather_bytes_per_rank": getattr(gather, "last_bytes", None)},

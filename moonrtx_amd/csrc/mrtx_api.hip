@@ -60,6 +60,10 @@ struct mrtx_ctx {
     uint64_t path_budget_bytes = 24ull << 30;   // hand-over buffers: frames that need more are rendered in sub-parts (MOONRT_PATH_MAX_GB)
     int path_nsub = 4, path_grp_log2 = 3;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
+    // launches with fewer samples than this keep their paths inside the render wave (same result, bit for bit): the three
+    // kernels + 5 120 persistent waves of the queue do not pay below ~8 M samples (4K: 1 spp 1.34 ms against 1.48, 2 spp 2.28 /
+    // 2.41, 4 spp 3.42 / 3.16; cfg1 0.33 / 0.53; tools/spp_sweep.py).  MOONRT_PATH_QUEUE_MIN overrides (0 = always the queue).
+    uint64_t path_queue_min = 8000000ull;
     int path_refill = 32, path_segmin = 16, path_hitmin = 16, path_waves_env = 0;   // cfg3 sweep: (8,24,16) 16.2 ms, (24,24,16) 14.7, (32,16,16) 14.5, (48,24,16) 21.5
     float* accum = nullptr;
     float* hits = nullptr;
@@ -449,6 +453,7 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
         if ((e = std::getenv("MOONRT_PATH_GRP")) && std::atoi(e) >= 0 && std::atoi(e) <= 10) c->path_grp_log2 = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_MAX_GB")) && std::atof(e) > 0.0) c->path_budget_bytes = (uint64_t)(std::atof(e) * 1073741824.0);
         if ((e = std::getenv("MOONRT_PATH_WAVES")) && std::atoi(e) >= 8) c->path_waves_env = std::atoi(e) / 8 * 8;
+        if ((e = std::getenv("MOONRT_PATH_QUEUE_MIN")) && std::atof(e) >= 0.0) c->path_queue_min = (uint64_t)std::atof(e);
     }
     c->tiles_x = (cfg->width + c->cfg.tile_w - 1) / c->cfg.tile_w;
     c->tiles_y = (cfg->height + c->cfg.tile_h - 1) / c->cfg.tile_h;
@@ -797,7 +802,11 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     // D6 (path_seg_max > 1): by default the path continues in path_kernel behind a queue (mode 2);
     // MRTX_F_INWAVE_PATHS keeps it inside the render wave (mode 1) -- same result bit for bit, slower.
     const int S = (int)c->prm.spp_per_launch;
-    const int mode = c->prm.path_seg_max > 1 ? ((c->prm.flags & MRTX_F_INWAVE_PATHS) ? 1 : 2) : 0;
+    int mode = c->prm.path_seg_max > 1 ? ((c->prm.flags & MRTX_F_INWAVE_PATHS) ? 1 : 2) : 0;
+    if (mode == 2) {
+        const uint64_t tiles = f.tile_list ? (uint64_t)f.n_active : (uint64_t)c->n_local;
+        if (tiles * (uint64_t)(f.tile_w * f.tile_h) * (uint64_t)S * (uint64_t)n_blocks < c->path_queue_min) mode = 1;
+    }
     double primary_ms = 0.0, paths_ms = 0.0;
     uint32_t launches = 0;
     if (mode != 2) {

@@ -12,6 +12,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 # contexts created by the tests keep the deterministic sample counters unless a test asks otherwise (the library's own
 # default is the production kernels, flags = 0)
 os.environ.setdefault("MOONRT_DEFAULT_FLAGS", "1")
+# ... and send even the small test frames through the path queue (the library keeps the paths of launches below ~8 M samples
+# inside the render wave: same result, one kernel instead of three)
+os.environ.setdefault("MOONRT_PATH_QUEUE_MIN", "0")
 
 
 def pytest_configure(config):

@@ -104,3 +104,19 @@ def test_hand_over_buffers_are_bounded_by_rendering_in_sub_parts(native_lib, rou
         if count:
             assert {k: st[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
         assert st["launches"] >= 3 * 4
+
+
+def test_small_launches_keep_their_paths_in_the_wave(native_lib, rough, monkeypatch):
+    """Below MOONRT_PATH_QUEUE_MIN samples (8 M by default) a launch runs ONE kernel with the paths inside the wave; above it
+    the three-kernel queue.  Same frame either way."""
+    s = named_scene("S1", 96, 64, spp_per_launch=16)
+    s.path_seg_min, s.path_seg_max = 2, 4
+    lin_o, hits_o, _ = render_oracle(s, rough)
+    monkeypatch.delenv("MOONRT_PATH_QUEUE_MIN", raising=False)
+    lin, hits, st, _ = render_hip(s, rough, flags=0)
+    assert st["launches"] == 1 and st["paths_ms"] == 0.0
+    assert_bit_equal(lin, lin_o, "automatic in-wave radiance"); assert_bit_equal(hits, hits_o, "automatic in-wave hits")
+    monkeypatch.setenv("MOONRT_PATH_QUEUE_MIN", "1000")
+    lin, hits, st, _ = render_hip(s, rough, flags=0)
+    assert st["launches"] == 3 and st["paths_ms"] > 0.0
+    assert_bit_equal(lin, lin_o, "queue radiance"); assert_bit_equal(hits, hits_o, "queue hits")
