@@ -1280,6 +1280,7 @@ render_kernel(const FrameC f, const PathQ pq) {
 #endif
 #ifdef MRTX_PATH_PROF   // measurement build only (tools/path_prof.py): block executions and lane counts of path_kernel
 __device__ unsigned long long g_pprof[16];
+__device__ unsigned long long g_pprof_t[16];   // [0..7] latest wave end per label, [8] earliest wave start (wall_clock64 ticks, 100 MHz), [9] waves
 #endif
 enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_BISECT, PS_ENDED, PS_HITWAIT, PS_SHADE };
 
@@ -1322,6 +1323,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     uint32_t pf[16];   // wave-uniform: iterations, then (executions, lanes) of refill / set-up / step / rare
 #pragma unroll
     for (int i = 0; i < 16; i++) pf[i] = 0;
+    if (lane == 0) atomicMin(&g_pprof_t[8], (unsigned long long)wall_clock64());
 #endif
 
     // per-lane path state
@@ -1614,6 +1616,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 16; i++) atomicAdd(&g_pprof[i], (unsigned long long)pf[i]);
+        atomicMax(&g_pprof_t[label], (unsigned long long)wall_clock64());
     }
 #endif
     if (STATS) {
@@ -2142,6 +2145,15 @@ extern "C" __attribute__((visibility("default"))) int mrtx_pprof_read(unsigned l
     if (reset) {
         unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(mrtx::g_pprof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int mrtx_pprof_times(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mrtx::g_pprof_t), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        z[8] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mrtx::g_pprof_t), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -15,17 +15,21 @@ scene = named_scene("S1", W, H, spp_per_launch=64); scene.path_seg_min, scene.pa
 lib = _lib.load()
 fn = lib.mrtx_pprof_read; fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 out = (C.c_ulonglong * 16)()
+ft = lib.mrtx_pprof_times; ft.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+tms = (C.c_ulonglong * 16)()
 settings = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(32, 16, 16)]
 for (refill, segmin, rare) in settings:
     os.environ.update(MOONRT_PATH_REFILL=str(refill), MOONRT_PATH_SEGMIN=str(segmin), MOONRT_PATH_HITMIN=str(rare))
     rt = MoonRT(W, H); rt.bind_dem(dem, dem_h, dem_w); rt.bind_color(col, *col_shape); rt.apply_scene(scene); rt.set_params(flags=int(os.environ.get("FLAGS", "0")))
-    rt.render(1); fn(out, 1)
-    rt.reset(); st = rt.render(1); fn(out, 1)
+    rt.render(1); fn(out, 1); ft(tms, 1)
+    rt.reset(); st = rt.render(1); fn(out, 1); ft(tms, 1)
     v = list(out)
     print(f"refill {refill} seg {segmin} rare {rare}: paths {st['paths_ms']:.2f} ms; iterations/wave {v[0]/5120:.0f}")
     for i, n in enumerate(("refill", "set-up", "step", "rare")):
         ex, ln = v[1 + 2 * i], v[2 + 2 * i]
         print(f"    {n:7s} executions {ex:12d} ({ex / max(1, v[0]):.2f} per iteration)  lanes waiting {ln / max(1, ex):5.1f}")
+    t = list(tms)
+    print("    last wave of each label ends after " + ", ".join(f"{(t[i] - t[8]) / 100.0:.0f}" for i in range(8)) + " us (first wave start = 0)")
     tot = sum(v[9:14])
     if tot:
         names = ("bookkeeping + refill", "set-up", "step", "segment end + march over", "rare")
