@@ -39,6 +39,20 @@ COUNT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "bounce_rays", "hei
               "background_fetches", "dem_fetches", "mip_fetches")
 
 
+def synth_starmap(h, w, seed=0x53544152, n_stars=400000):
+    """RGBA8 stand-in for the reference's starmap_16k.tif (main.py:36, bound by moon_renderer.py:604-607): black sky, a dim
+    milky band, stars of random colour and brightness."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    img = np.zeros((h, w, 4), np.uint8)
+    band = (6.0 * np.exp(-((np.arange(h) - h / 2) / (h / 14)) ** 2)).astype(np.uint8)
+    img[:, :, :3] = band[:, None, None]
+    r, c = rng.integers(0, h, n_stars), rng.integers(0, w, n_stars)
+    img[r, c, :3] = np.minimum(255, rng.gamma(0.6, 40.0, (n_stars, 1)) + rng.integers(0, 30, (n_stars, 3))).astype(np.uint8)
+    img[:, :, 3] = 255
+    return img
+
+
 def source_hash():
     """Identity of the kernel sources a profile was taken with (the GPU box has no .git)."""
     h = hashlib.sha256()

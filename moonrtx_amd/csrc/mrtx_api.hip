@@ -88,6 +88,7 @@ struct mrtx_ctx {
     std::vector<int32_t> keep_uploaded;  // what tile_list_dev holds
     std::vector<int32_t> keep_cached;    // cull result for scene_version == cull_version
     uint64_t culled_px_cached = 0;
+    int keep_front_cached = 0;           // leading entries of keep_cached that can see the Moon / Sun / an overlay (the rest is sky)
     uint64_t scene_version = 1, cull_version = 0;   // bumped by every setter that can change the cull
     std::vector<uint8_t> tile_dirty;     // local tiles written since the buffers were last zeroed
     // gather layout: with the sky cull in force only ACTIVE tiles travel (every rank derives every rank's list from the
@@ -329,8 +330,13 @@ int build_capsule_bins(mrtx_ctx* c) {
 // cone of its view directions (tile-centre direction, half-angle = largest corner angle + 5 % + 1e-4 rad, pixel
 // extents included so every jittered sample is inside) is disjoint from both objects' cones as seen from the eye.
 // Returns the local tile indices to render and the number of pixels culled.
-void cull_tiles(const mrtx_ctx* c, int rank, std::vector<int32_t>& keep, uint64_t& culled_px) {
+// With an environment texture bound nothing is culled, but the classification still pays: the tiles that can only see
+// the sky go to the END of the list (n_front = how many can see more), so that the deferred-path pipeline -- buffers sized
+// per wave-job, persistent waves walking every group of blocks -- is set up for the Moon's tiles only and the sky gets one
+// plain launch (cfg3 with the reference's star map: 8 100 tiles, 3 056 of them with the Moon in view).
+void cull_tiles(const mrtx_ctx* c, int rank, std::vector<int32_t>& keep, uint64_t& culled_px, int* n_front = nullptr) {
     keep.clear(); culled_px = 0;
+    std::vector<int32_t> sky;
     const int n_local = (c->n_tiles - rank + c->cfg.world - 1) / c->cfg.world;
     const bool own = rank == c->cfg.rank;   // overlay bins exist for the own tiles only (gather_layout() switches off with overlays)
     const int W = c->cfg.width, H = c->cfg.height;
@@ -354,7 +360,8 @@ void cull_tiles(const mrtx_ctx* c, int rank, std::vector<int32_t>& keep, uint64_
         for (int i = 0; i < 3; i++) cn.ax[i] = d[i] / dist;
         cn.half = std::asin(radii[k] / dist);
     }
-    const bool everything = c->bg != nullptr || cones[0].all || cones[1].all;
+    const bool everything = cones[0].all || cones[1].all;
+    const bool sky_rendered = c->bg != nullptr;
     auto dir = [&](double px, double py, double o[3]) {
         const double sx = px * 2.0 / W - 1.0, sy = 1.0 - py * 2.0 / H;
         for (int i = 0; i < 3; i++) o[i] = wv[i] + sx * (uv[i] * (th * aspect)) + sy * (vv[i] * th);
@@ -397,11 +404,15 @@ void cull_tiles(const mrtx_ctx* c, int rank, std::vector<int32_t>& keep, uint64_
                 on_ring = rho >= 0.85 && rho <= 1.05;
             }
             (on_ring ? ring : keep).push_back(lt);
+        } else if (sky_rendered) {
+            sky.push_back(lt);
         } else {
             culled_px += (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
         }
     }
     keep.insert(keep.begin(), ring.begin(), ring.end());
+    if (n_front) *n_front = (int)keep.size();
+    keep.insert(keep.end(), sky.begin(), sky.end());
 }
 
 int check_vec(const double* p) {
@@ -757,13 +768,14 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     bool culling = false;
     if (!(c->prm.flags & MRTX_F_NO_CULL)) {
         if (c->cull_version != c->scene_version) {
-            cull_tiles(c, c->cfg.rank, c->keep_cached, c->culled_px_cached);
+            cull_tiles(c, c->cfg.rank, c->keep_cached, c->culled_px_cached, &c->keep_front_cached);
             c->cull_version = c->scene_version;
         }
         culled_px = c->culled_px_cached;
         culling = true;   // the list also carries the launch ORDER, so it is used even when it holds every tile
     }
     const std::vector<int32_t>& keep = c->keep_cached;
+    int moon_n = -1;                     // leading tiles of this launch's list that can see more than sky (-1: no split known)
     if (culling) {
         if (keep != c->keep_uploaded) {
             if (!keep.empty()) {
@@ -782,6 +794,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         }
         f.tile_list = c->tile_list_dev + pa;
         f.n_active = pb - pa;
+        if (c->bg != nullptr) moon_n = std::max(0, std::min(pb, c->keep_front_cached) - pa);
         // culled tiles are all-zero by construction: clear only if an earlier view rendered into one of them
         std::vector<uint8_t> kept((size_t)c->n_local, 0);
         for (int32_t lt : keep) kept[(size_t)lt] = 1;
@@ -803,9 +816,16 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     // MRTX_F_INWAVE_PATHS keeps it inside the render wave (mode 1) -- same result bit for bit, slower.
     const int S = (int)c->prm.spp_per_launch;
     int mode = c->prm.path_seg_max > 1 ? ((c->prm.flags & MRTX_F_INWAVE_PATHS) ? 1 : 2) : 0;
+    FrameC fsky = f;                     // mode 2 with an environment map: the sky tiles get one plain launch of their own
+    bool have_sky = false;
     if (mode == 2) {
-        const uint64_t tiles = f.tile_list ? (uint64_t)f.n_active : (uint64_t)c->n_local;
+        const uint64_t tiles = f.tile_list ? (uint64_t)(moon_n >= 0 ? moon_n : f.n_active) : (uint64_t)c->n_local;
         if (tiles * (uint64_t)(f.tile_w * f.tile_h) * (uint64_t)S * (uint64_t)n_blocks < c->path_queue_min) mode = 1;
+        else if (moon_n >= 0 && moon_n < f.n_active) {
+            fsky.tile_list = f.tile_list + moon_n; fsky.n_active = f.n_active - moon_n;
+            f.n_active = moon_n;
+            have_sky = true;
+        }
     }
     double primary_ms = 0.0, paths_ms = 0.0;
     uint32_t launches = 0;
@@ -880,7 +900,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         const int nw = c->path_waves_env ? c->path_waves_env : c->path_waves[wi];
         const size_t n_ev = (size_t)n_blocks * (size_t)n_sub * 3;
         while (c->evs.size() < n_ev) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->evs.push_back(e); }
-        for (int32_t b = 0; b < n_blocks; b++) {
+        for (int32_t b = 0; b < n_blocks && f.n_active > 0; b++) {
             for (int s = 0; s < n_sub; s++) {
                 hipEvent_t* ev = &c->evs[((size_t)b * (size_t)n_sub + (size_t)s) * 3];
                 FrameC fb = fs[(size_t)s];
@@ -898,6 +918,12 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
                 HIPCHK(c, hipEventRecord(ev[2], c->stream));
             }
         }
+        if (have_sky) {   // nothing but the environment can be seen from these tiles: no paths, no records
+            fsky.first_block = c->blocks_done; fsky.n_blocks = (uint32_t)n_blocks;
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            HIPCHK(c, mrtx_launch_render(fsky, S, stats, 0, false, nullptr, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        }
         // path_kernel's watchdog (stats[15]): a wave gave up after 2^24 iterations -- the frame is incomplete.  Read through
         // pinned memory on the stream, so that the one synchronisation below covers it (no second blocking copy per call).
         if (!c->wd_host) HIPCHK(c, hipHostMalloc((void**)&c->wd_host, sizeof(unsigned long long), hipHostMallocDefault));
@@ -910,13 +936,18 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
                 return fail(c, MRTX_E_DEVICE, "path_kernel watchdog: %llu wave(s) did not finish their paths", wd);
             }
         }
-        for (size_t i = 0; i < (size_t)n_blocks * (size_t)n_sub; i++) {
+        if (have_sky) {
+            float a = 0.0f;
+            HIPCHK(c, hipEventElapsedTime(&a, c->ev0, c->ev1));
+            primary_ms += a;
+        }
+        for (size_t i = 0; i < (f.n_active > 0 ? (size_t)n_blocks * (size_t)n_sub : 0); i++) {
             float a = 0.0f, p = 0.0f;
             HIPCHK(c, hipEventElapsedTime(&a, c->evs[i * 3], c->evs[i * 3 + 1]));
             HIPCHK(c, hipEventElapsedTime(&p, c->evs[i * 3 + 1], c->evs[i * 3 + 2]));
             primary_ms += a; paths_ms += p;
         }
-        launches = 3u * (uint32_t)n_blocks * (uint32_t)n_sub;
+        launches = (f.n_active > 0 ? 3u * (uint32_t)n_blocks * (uint32_t)n_sub : 0u) + (have_sky ? 1u : 0u);
     }
     if (part == n_parts - 1) c->blocks_done += (uint32_t)n_blocks;
     if (out) {

@@ -1282,7 +1282,7 @@ render_kernel(const FrameC f, const PathQ pq) {
 __device__ unsigned long long g_pprof[16];
 __device__ unsigned long long g_pprof_t[16];   // [0..7] latest wave end per label, [8] earliest wave start (wall_clock64 ticks, 100 MHz), [9] waves
 #endif
-enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_BISECT, PS_ENDED, PS_HITWAIT, PS_SHADE };
+enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_BISECT, PS_ENDED, PS_HITWAIT, PS_SHADE, PS_ESCAPED };
 
 // The march inside path_kernel is cut at STEP granularity, not at segment granularity: within one 16-step segment
 // the rays of a wave need anything from 0 to 16 dependent DEM fetches (mean ~4), and a wave that steps a whole
@@ -1359,7 +1359,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             break;
         }
         const int n_seg = __popcll(__ballot(state == PS_NEEDSEG)), n_step = __popcll(__ballot(state == PS_STEP || state == PS_BISECT));
-        const int n_rare = __popcll(__ballot(state == PS_HITWAIT || state == PS_SHADE));
+        const int n_rare = __popcll(__ballot(state == PS_HITWAIT || state == PS_SHADE || state == PS_ESCAPED));
         // stepping is cheap and runs whenever a lane can step; the others wait for their thresholds, or until nothing cheaper
         // can make progress.  (Running only the block most lanes wait for was measured: more iterations, 18.9 ms against 17.7.)
         const bool do_step = n_step > 0;
@@ -1559,10 +1559,13 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 j = f.nbis;
                 if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
                 state = f.nbis > 0 ? PS_BISECT : PS_HITWAIT;
+            } else if (CF(f)->bg) {
+                // the path left the Moon and an environment map is bound: its look-up (a dependent fetch from a large
+                // texture) waits with the rare steps instead of stalling every iteration
+                state = PS_ESCAPED;
             } else {
-                // the path left the Moon: Sun disk / environment along the ray, if there is any
                 float e0, e1, e2;
-                if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {
+                if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {   // the Sun disk
                     if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
                     c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
                 }
@@ -1576,6 +1579,19 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         // continued or ended (~250 VALU).  They wait until enough lanes need them -- or nothing is marching.
         PPROF_T(12);
         if (do_rare) {
+            if (state == PS_ESCAPED) {
+                float e0, e1, e2;
+                if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {
+                    // a black texel adds nothing (fmaf(t, 0, c) == c for finite t): the sample's radiance need not be touched
+                    const bool nothing = (e0 == 0.0f) & (e1 == 0.0f) & (e2 == 0.0f) & ((t0r + t1r + t2r) < __builtin_inff());
+                    if (!nothing) {
+                        if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                        c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
+                    }
+                }
+                if (have_c) { pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2; }
+                state = PS_IDLE;
+            }
             if (state == PS_HITWAIT) {
                 const float blo = bis_lo;                  // the bisected bracket's upper side (PS_BISECT)
                 hit_vertex<STATS, WIDE>(f, fmaf(blo, m.da, m.oa), fmaf(blo, m.db, m.ob), fmaf(blo, m.dc, m.oc), v, cnt);

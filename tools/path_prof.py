@@ -21,6 +21,11 @@ settings = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(32, 
 for (refill, segmin, rare) in settings:
     os.environ.update(MOONRT_PATH_REFILL=str(refill), MOONRT_PATH_SEGMIN=str(segmin), MOONRT_PATH_HITMIN=str(rare))
     rt = MoonRT(W, H); rt.bind_dem(dem, dem_h, dem_w); rt.bind_color(col, *col_shape); rt.apply_scene(scene); rt.set_params(flags=int(os.environ.get("FLAGS", "0")))
+    if os.environ.get("STARMAP"):     # the reference's environment (moon_renderer.py:604-607); STARMAP=black: an all-zero one
+        import bench
+        sm = bench.synth_starmap(8192, 16384)
+        if os.environ["STARMAP"] == "black": sm[:, :, :3] = 0
+        rt.upload_background(sm)
     rt.render(1); fn(out, 1); ft(tms, 1)
     rt.reset(); st = rt.render(1); fn(out, 1); ft(tms, 1)
     v = list(out)
