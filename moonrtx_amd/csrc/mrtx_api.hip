@@ -816,28 +816,32 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     // MRTX_F_INWAVE_PATHS keeps it inside the render wave (mode 1) -- same result bit for bit, slower.
     const int S = (int)c->prm.spp_per_launch;
     int mode = c->prm.path_seg_max > 1 ? ((c->prm.flags & MRTX_F_INWAVE_PATHS) ? 1 : 2) : 0;
-    FrameC fsky = f;                     // mode 2 with an environment map: the sky tiles get one plain launch of their own
-    bool have_sky = false;
     if (mode == 2) {
         const uint64_t tiles = f.tile_list ? (uint64_t)(moon_n >= 0 ? moon_n : f.n_active) : (uint64_t)c->n_local;
         if (tiles * (uint64_t)(f.tile_w * f.tile_h) * (uint64_t)S * (uint64_t)n_blocks < c->path_queue_min) mode = 1;
-        else if (moon_n >= 0 && moon_n < f.n_active) {
-            fsky.tile_list = f.tile_list + moon_n; fsky.n_active = f.n_active - moon_n;
-            f.n_active = moon_n;
-            have_sky = true;
-        }
+    }
+    // With an environment map the sky-only tiles at the end of the list get a launch of their own (render_kernel<MODE 3>: a
+    // sample is its environment texel): a small kernel at full occupancy, and the path pipeline is set up for the rest only.
+    FrameC fsky = f;
+    bool have_sky = false;
+    if (moon_n >= 0 && moon_n < f.n_active) {
+        fsky.tile_list = f.tile_list + moon_n; fsky.n_active = f.n_active - moon_n;
+        fsky.first_block = c->blocks_done; fsky.n_blocks = (uint32_t)n_blocks;
+        f.n_active = moon_n;
+        have_sky = true;
     }
     double primary_ms = 0.0, paths_ms = 0.0;
     uint32_t launches = 0;
     if (mode != 2) {
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-        HIPCHK(c, mrtx_launch_render(f, S, stats, mode, overlay, nullptr, c->stream));
+        if (f.n_active > 0 || !f.tile_list) HIPCHK(c, mrtx_launch_render(f, S, stats, mode, overlay, nullptr, c->stream));
+        if (have_sky) HIPCHK(c, mrtx_launch_render(fsky, S, stats, 3, false, nullptr, c->stream));
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         primary_ms = ms;
-        launches = 1;
+        launches = ((f.n_active > 0 || !f.tile_list) ? 1u : 0u) + (have_sky ? 1u : 0u);
     } else {
         // The hand-over buffers are sized for the worst case (64 bytes for each of the 64 lanes of every wave-job of the
         // launch: 12 GB for the whole-disc cfg3 frame, 129 GB for a cfg4 frame whose every pixel is on the Moon).  A frame
@@ -919,9 +923,8 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             }
         }
         if (have_sky) {   // nothing but the environment can be seen from these tiles: no paths, no records
-            fsky.first_block = c->blocks_done; fsky.n_blocks = (uint32_t)n_blocks;
             HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-            HIPCHK(c, mrtx_launch_render(fsky, S, stats, 0, false, nullptr, c->stream));
+            HIPCHK(c, mrtx_launch_render(fsky, S, stats, 3, false, nullptr, c->stream));
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         }
         // path_kernel's watchdog (stats[15]): a wave gave up after 2^24 iterations -- the frame is incomplete.  Read through

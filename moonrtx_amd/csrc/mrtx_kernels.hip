@@ -849,7 +849,8 @@ struct SampleOut {
 };
 
 // MODE: 0 = direct light only, 1 = the whole path inside this wave (BOUNCE), 2 = direct light + hand-over of the
-// vertex to path_kernel (DEFER)
+// vertex to path_kernel (DEFER), 3 = SKY: the host has proven that no sample of this tile can meet the Moon's bounding
+// sphere, the Sun disk or an overlay tube (cull_tiles), so a sample is its environment texel and nothing else
 template <bool STATS, bool WIDE, int MODE, bool OVERLAY>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
@@ -874,6 +875,10 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     float dz = fmaf(sy, CF(f)->Vy[2], fmaf(sx, CF(f)->Ux[2], CF(f)->Wd[2]));
     const float inv_len = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
     dx = dx * inv_len; dy = dy * inv_len; dz = dz * inv_len;
+    if (MODE == 3) {
+        if (CF(f)->bg) env_lookup<STATS>(f, dx, dy, dz, o.c0, o.c1, o.c2, cnt);  // D7
+        return;
+    }
 
     // float64 entry into the bounding sphere: the eye sits ~30 radii away, float32 would cost metres
     const double Dx = (double)dx, Dy = (double)dy, Dz = (double)dz;
@@ -1099,6 +1104,9 @@ __device__ __forceinline__ float tree_sum(float v) {
 #ifndef MRTX_WG_WAVES
 #define MRTX_WG_WAVES 1
 #endif
+#ifndef MRTX_SKY_WG_TILE
+#define MRTX_SKY_WG_TILE 8    // MODE 3: a wave walks an 8x8-pixel block (a sky sample is ~150 instructions: one pixel per
+#endif                        // workgroup is bound by the dispatcher, 1.9 ms for the 5 000 sky tiles of cfg3 + star map)
 #ifndef MRTX_MIN_WAVES
 #define MRTX_MIN_WAVES 4   // 4 waves/SIMD (128-VGPR budget): 13.57 ms at cfg3 against 13.87 with 5 (96), 14.8 with 6; 3 = 4
 #endif
@@ -1131,7 +1139,8 @@ render_kernel(const FrameC f, const PathQ pq) {
     constexpr int PH = P / PW;
     // workgroup tile edge in pixels: MRTX_WG_TILE, but at least two jobs wide so the 4 waves all have work
     constexpr int WGMIN = MRTX_WG_WAVES > 2 ? 2 * PW : MRTX_WG_WAVES > 1 ? 2 * PH : PW;
-    constexpr int WGT = (WGMIN > MRTX_WG_TILE) ? WGMIN : MRTX_WG_TILE;
+    constexpr int WGTILE = MODE == 3 ? MRTX_SKY_WG_TILE : MRTX_WG_TILE;
+    constexpr int WGT = (WGMIN > WGTILE) ? WGMIN : WGTILE;
     constexpr int WGS = WGT == 16 ? 4 : WGT == 8 ? 3 : WGT == 4 ? 2 : WGT == 2 ? 1 : 0;
     constexpr int JX = WGT / PW, JY = WGT / PH, NJOBS = JX * JY;
     __shared__ unsigned int lds_cnt[ST_N];
@@ -2047,12 +2056,13 @@ __global__ void mip_pair_kernel(const float* __restrict__ mip, float2* __restric
 // launch wrappers (called from mrtx_api.hip)
 extern "C++" {
 // geometry of a render launch for S samples per pixel per wave: wave-jobs ("chunks") = grid x jobs per wave
-static void render_geometry(const FrameC& f, int S, int& xcd_share, unsigned& grid, int& njobs, int& pw_log2) {
+static void render_geometry(const FrameC& f, int S, int& xcd_share, unsigned& grid, int& njobs, int& pw_log2, int mode = 0) {
     const int P = 64 / S;
     const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1;
     const int PH = P / PW;
     const int wgmin = MRTX_WG_WAVES > 2 ? 2 * PW : MRTX_WG_WAVES > 1 ? 2 * PH : PW;
-    const int wgt = (wgmin > MRTX_WG_TILE) ? wgmin : MRTX_WG_TILE;
+    const int wgtile = mode == 3 ? MRTX_SKY_WG_TILE : MRTX_WG_TILE;
+    const int wgt = (wgmin > wgtile) ? wgmin : wgtile;
     const int subs = (f.tile_w / wgt) * (f.tile_h / wgt);
     xcd_share = (MRTX_XCD_SHARE && (subs & 7) == 0 && f.n_active < MRTX_XCD_SHARE_BELOW) ? 1 : 0;   // see the remap in render_kernel
     const int groups = xcd_share ? f.n_active : (f.n_active + 7) / 8 * 8;
@@ -2068,11 +2078,12 @@ uint64_t mrtx_path_chunks(const FrameC& f, int S, uint32_t* grid_a, int* njobs_l
     if (njobs_log2) *njobs_log2 = njobs == 2 ? 1 : 0;
     return (uint64_t)grid * (uint64_t)njobs;
 }
-// mode: 0 = direct light only, 1 = whole paths inside the wave, 2 = direct light + hand-over to path_kernel (pq)
+// mode: 0 = direct light only, 1 = whole paths inside the wave, 2 = direct light + hand-over to path_kernel (pq),
+// 3 = sky tiles (environment texel only)
 hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, int mode, bool overlay, const PathQ* pq, hipStream_t st) {
     FrameC fr = f;
     int njobs, pwl; unsigned gx;
-    render_geometry(f, S, fr.xcd_share, gx, njobs, pwl);
+    render_geometry(f, S, fr.xcd_share, gx, njobs, pwl, mode);
     const dim3 grid(gx), block(64 * MRTX_WG_WAVES);
     if (grid.x == 0) return hipSuccess;
     PathQ q;
@@ -2090,7 +2101,9 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, int mode, bool
 #define MRTX_CASE2(SV, MD) if (overlay) { MRTX_CASE3(SV, MD, true) } else { MRTX_CASE3(SV, MD, false) }
 #define MRTX_CASE(SV)                                                  \
     case SV:                                                           \
-        if (mode == 1) { MRTX_CASE2(SV, 1) } else if (mode == 2) { MRTX_CASE2(SV, 2) } else { MRTX_CASE2(SV, 0) }   \
+        if (mode == 1) { MRTX_CASE2(SV, 1) } else if (mode == 2) { MRTX_CASE2(SV, 2) }                              \
+        else if (mode == 3) { if (stats) MRTX_LAUNCH(SV, true, false, 3, false); else MRTX_LAUNCH(SV, false, false, 3, false); }   \
+        else { MRTX_CASE2(SV, 0) }   \
         break;
     switch (S) {
         MRTX_CASE(1) MRTX_CASE(2) MRTX_CASE(4) MRTX_CASE(8) MRTX_CASE(16) MRTX_CASE(32) MRTX_CASE(64)
