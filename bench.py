@@ -297,6 +297,19 @@ def main():
         rt.apply_scene(scene)
         rt.set_params(flags=base_flags)
 
+    # ... and the headline frame with the environment the reference binds by default (moon_renderer.py:604-607: a 16384x8192
+    # star map as "TextureEnvironment"): the sky is no longer black (every tile is dispatched; the sky-only ones as
+    # render_kernel<MODE 3>), every path that leaves the Moon looks its texel up
+    starmap = None
+    if world == 1 and seg[1] > 1 and not args.no_secondary and args.workload == "cfg3":
+        rt.upload_background(synth_starmap(8192, 16384))
+        step()
+        e4, k4 = timed(3)
+        starmap = {"scene": f"{args.scene} + synthetic 16384x8192 RGBA8 star map bound as the environment, path_seg_range {list(seg)}",
+                   "value": round(W * H * spp / (e4 / 3) / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(e4 / 3 * 1e3, 3),
+                   "kernel_ms": round(k4["kernel_ms"], 3), "primary_ms": round(k4["primary_ms"], 3), "paths_ms": round(k4["paths_ms"], 3)}
+        rt.upload_background(None)
+
     facade = None
     if rank == 0 and world == 1 and args.workload == "cfg3" and not args.no_secondary:
         try:
@@ -407,6 +420,8 @@ def main():
             out["also"] = also
         if zoom is not None:
             out["also_zoomed"] = zoom
+        if starmap is not None:
+            out["also_starmap"] = starmap
         if facade is not None:
             out["facade"] = facade
         if world == 1 and not args.no_cpu_baseline:
