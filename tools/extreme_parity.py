@@ -3,6 +3,7 @@
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("MOONRT_PATH_QUEUE_MIN", "0")   # these small frames go through the path queue too (as under pytest)
 import numpy as np
 from common import STAT_KEYS, assert_bit_equal, render_hip, render_oracle
 from moonrtx_amd.scene import named_scene

@@ -9,6 +9,7 @@ import time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("MOONRT_PATH_QUEUE_MIN", "0")   # these small frames go through the path queue too (as under pytest)
 import fuzz_cases   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
