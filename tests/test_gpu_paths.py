@@ -120,3 +120,22 @@ def test_small_launches_keep_their_paths_in_the_wave(native_lib, rough, monkeypa
     lin, hits, st, _ = render_hip(s, rough, flags=0)
     assert st["launches"] == 3 and st["paths_ms"] > 0.0
     assert_bit_equal(lin, lin_o, "queue radiance"); assert_bit_equal(hits, hits_o, "queue hits")
+
+
+def test_sky_tiles_get_their_own_launch_when_an_environment_is_bound(native_lib, rough):
+    """moon_renderer.py:604-607 binds a star map: nothing can be culled any more, but the tiles that can only see the sky are
+    rendered by render_kernel<MODE 3> (environment texel only) and stay out of the path queue -- same frame as the oracle."""
+    bg = np.random.default_rng(5).integers(0, 255, (48, 96, 4), dtype=np.uint8)
+    bg[::3] = 0                                          # black texels: an escaping path adds exactly nothing there
+    s = named_scene("S1", 160, 128, spp_per_launch=16)
+    s.vfov_deg = 12.0                                    # the disc covers the middle tiles only
+    for seg, launches in (((2, 4), 4), ((1, 1), 2)):
+        s.path_seg_min, s.path_seg_max = seg
+        lin_o, hits_o, st_o = render_oracle(s, rough, None, bg)
+        for count in (_lib.F_COUNT_STATS, 0):
+            lin, hits, st, _ = render_hip(s, rough, None, bg, flags=count)
+            assert_bit_equal(lin, lin_o, f"sky split {seg} radiance"); assert_bit_equal(hits, hits_o, f"sky split {seg} hits")
+            if count:
+                assert {k: st[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
+            assert st["launches"] == launches, st["launches"]
+        assert st_o["background_fetches"] > st_o["primary_hits"] > 0
