@@ -139,3 +139,32 @@ def test_sky_tiles_get_their_own_launch_when_an_environment_is_bound(native_lib,
                 assert {k: st[k] for k in STAT_KEYS} == {k: st_o[k] for k in STAT_KEYS}
             assert st["launches"] == launches, st["launches"]
         assert st_o["background_fetches"] > st_o["primary_hits"] > 0
+
+
+def test_two_ranks_with_environment_and_paths(native_lib, rough):
+    """What FrameGather drives on two GPUs when an environment map is bound (full gather layout, no parts), here on two
+    contexts of one GPU: (2,4) paths behind the queue, the sky tiles at the end of every rank's list rendered by their own
+    launch -- the reassembled frame equals the oracle's."""
+    from moonrtx_amd.renderer import MoonRT, DeviceBuffer
+    bg = np.random.default_rng(9).integers(0, 255, (40, 80, 4), dtype=np.uint8)
+    s = named_scene("S1", 192, 128, spp_per_launch=16)
+    s.vfov_deg = 9.0
+    s.path_seg_min, s.path_seg_max = 2, 4
+    lin_o, hits_o, _ = render_oracle(s, rough, None, bg)
+    world = 2
+    rts = [MoonRT(s.width, s.height, rank=r, world=world, tile=(16, 16)) for r in range(world)]
+    bufs = [DeviceBuffer(rt.shard_bytes()) for rt in rts]
+    try:
+        for rt, buf in zip(rts, bufs):
+            rt.upload_dem(rough); rt.upload_background(bg); rt.apply_scene(s); rt.set_params(flags=0)
+            assert rt.shard_parts(2) == 1                 # an environment map needs every tile: the full layout, no parts
+            rt.reset()
+            st = rt.render(1)
+            assert st["launches"] == 4                    # render + paths + resolve for the Moon's tiles, one for the sky
+            rt.pack_shard(buf.ptr)
+        rts[0].unpack_all([buf.ptr for buf in bufs])
+        assert_bit_equal(rts[0].read_linear(), lin_o, "2 ranks, environment, paths: radiance")
+        assert_bit_equal(rts[0].read_hits(), hits_o, "2 ranks, environment, paths: hits")
+    finally:
+        for rt in rts:
+            rt.close()
