@@ -786,8 +786,10 @@ __device__ __forceinline__ void escaped_path(const FrameC& f, float boa, float b
 // centre (relative to the centre), d = unit direction; per capsule the origin is re-centred once more at the
 // capsule's first endpoint so the quadratic stays well-conditioned for radii ~1e-2 at a 300-unit eye distance.
 // The loop is wave-uniform (every lane walks the same bin), capsule data come through scalar loads.
+// Only intersections IN FRONT OF THE EYE count (parameter > smin = the eye's parameter on this ray): a tube behind a camera
+// that sits inside the shell of tubes must not shadow the one in view (the host's per-tile bins never hold it anyway).
 __device__ __forceinline__ float nearest_capsule(const FrameC& f, int lt, float r0, float r1, float r2v, float dx,
-                                                 float dy, float dz, int& which) {
+                                                 float dy, float dz, float smin, int& which) {
     typedef const __attribute__((address_space(4))) float* CFloat;
     typedef const __attribute__((address_space(4))) int32_t* CInt;
     const CInt off = (CInt)CF(f)->caps_off;
@@ -832,7 +834,7 @@ __device__ __forceinline__ float nearest_capsule(const FrameC& f, int lt, float 
         }
         if (have) {
             const float sc = ta + cand;
-            if (sc < best) { best = sc; which = k; }
+            if (sc > smin && sc < best) { best = sc; which = k; }
         }
     }
     return which >= 0 ? best : -1.0e30f;
@@ -905,8 +907,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     if (OVERLAY) {
         tc0 = -b * (double)(1.0f / (float)a);
         cr0 = (float)(CF(f)->oc[0] + tc0 * Dx); cr1 = (float)(CF(f)->oc[1] + tc0 * Dy); cr2 = (float)(CF(f)->oc[2] + tc0 * Dz);
-        cap_s = nearest_capsule(f, lt, cr0, cr1, cr2, dx, dy, dz, cap);
-        if (cap >= 0 && !(cap_s > (float)(-tc0))) cap = -1;   // behind the eye
+        cap_s = nearest_capsule(f, lt, cr0, cr1, cr2, dx, dy, dz, (float)(-tc0), cap);   // nearest one in front of the eye
         cap_front = cap >= 0 && (!on_sphere || cap_s < (float)(t0 - tc0));
     }
     bool hit = false;

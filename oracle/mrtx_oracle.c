@@ -521,7 +521,7 @@ static float direct_light(const OrcScene* s, const Frame* f, const Vertex* v, fl
  * centre), d = unit direction; per capsule the origin is re-centred once more at the capsule's first endpoint
  * (ta = (a - ro).d, oa = (ro - a) + ta d) so that the quadratic stays well-conditioned for radii ~1e-2 at a
  * 300-unit eye distance.  Returns the parameter relative to `ro` (or -1e30) and the index of the capsule. */
-static float nearest_capsule(const OrcScene* s, const Frame* f, const float ro[3], float dx, float dy, float dz, int* which) {
+static float nearest_capsule(const OrcScene* s, const Frame* f, const float ro[3], float dx, float dy, float dz, float smin, int* which) {
     float best = 1.0e30f;
     int k;
     *which = -1;
@@ -562,7 +562,7 @@ static float nearest_capsule(const OrcScene* s, const Frame* f, const float ro[3
         }
         if (have) {
             float sc = ta + cand;
-            if (sc < best) { best = sc; *which = k; }
+            if (sc > smin && sc < best) { best = sc; *which = k; }   /* in front of the eye only */
         }
     }
     (void)f;
@@ -612,8 +612,7 @@ static void trace_sample(const OrcScene* s, const Frame* f, int x, int y, uint32
     if (s->n_caps > 0) {
         tc0 = -b * (double)(1.0f / (float)a);   /* closest approach to the Moon centre (float32 reciprocal: a ~ 1) */
         cro[0] = (float)(f->oc[0] + tc0 * Dx); cro[1] = (float)(f->oc[1] + tc0 * Dy); cro[2] = (float)(f->oc[2] + tc0 * Dz);
-        cap_s = nearest_capsule(s, f, cro, dx, dy, dz, &cap);
-        if (cap >= 0 && !(cap_s > (float)(-tc0))) cap = -1;            /* behind the eye */
+        cap_s = nearest_capsule(s, f, cro, dx, dy, dz, (float)(-tc0), &cap);   /* the nearest one in front of the eye */
     }
     int cap_front = cap >= 0 && (!on_sphere || cap_s < (float)(t0 - tc0));
     int hit = 0;

@@ -1,7 +1,9 @@
 """Randomised parity: a fixed-seed slice of tests/fuzz_cases.py through the HIP path and the oracle, bit for bit.
 Includes seed 1 case 116, which exposed a shadow ray whose origin (hit + scene_epsilon * normal on a D = 1 texel) sits
 just outside the bounding sphere and heads inward: the march ends at step 1 by the spec and must not resume where the
-skipped steps dip back inside."""
+skipped steps dip back inside -- and seed 430 case 11: a camera inside the shell of overlay tubes, one tube behind the eye on
+the line of sight of another: only intersections in front of the eye count (the round-1 spec picked the nearest along the whole
+line and then dropped it, hiding the tube in view; the kernel's per-tile bins never held the one behind and showed it)."""
 import itertools
 
 import pytest
@@ -18,4 +20,5 @@ def test_random_cases_match_the_oracle(native_lib):
             total += fuzz_cases.check_case(c)["primary_hits"]
     for c in itertools.islice(fuzz_cases.cases(7), 25):
         total += fuzz_cases.check_case(c)["primary_hits"]
+    total += fuzz_cases.check_case(next(itertools.islice(fuzz_cases.cases(430), 11, 12)))["primary_hits"]
     assert total > 100000
