@@ -89,13 +89,18 @@ def cases(seed):
     dict(capsules, world, parts) drawn from a second stream, so case k of a seed keeps its scene as options are added."""
     rng = np.random.default_rng(seed)
     case = 0
+    import os
+    exotic = bool(os.environ.get("FUZZ_EXOTIC"))   # campaign option: the rare combinations (camera inside the shell of overlay
+    p_bg, p_caps, p_inside = (0.7, 0.7, 0.5) if exotic else (0.3, 0.25, 0.12)   # tubes, environment map, paths) in most cases
     while True:
         dem = random_dem(rng)
         col = (rng.integers(0, 256, (int(rng.integers(2, 40)), int(rng.integers(2, 70)), 4), dtype=np.uint8)
                if rng.random() < 0.6 else None)
         bg = (rng.integers(0, 256, (int(rng.integers(1, 20)), int(rng.integers(1, 40)), 4), dtype=np.uint8)
-              if rng.random() < 0.3 else None)
+              if rng.random() < p_bg else None)
         s = random_scene(rng)
+        if exotic and s.path_seg_max <= 1 and rng.random() < 0.7:
+            s.path_seg_min = int(rng.integers(1, 4)); s.path_seg_max = int(rng.integers(max(2, s.path_seg_min), 5))
         flags = _lib.F_COUNT_STATS
         for f, p in ((_lib.F_FORCE_WIDE, 0.3), (_lib.F_NO_SKIP, 0.15), (_lib.F_NO_CULL, 0.15), (_lib.F_NO_SORT, 0.15)):
             if rng.random() < p:
@@ -104,7 +109,7 @@ def cases(seed):
         blocks = (1,) if rng.random() < 0.7 else (1, 2)
         rng2 = np.random.default_rng([seed, case, 77])
         capsules = None
-        if rng2.random() < 0.25:                    # overlay tubes outside the bounding sphere (D11)
+        if rng2.random() < p_caps:                  # overlay tubes outside the bounding sphere (D11)
             n = int(rng2.integers(1, 12))
             caps = np.zeros((n, 12), np.float32)
             ctr = np.asarray(s.center, float)
@@ -118,7 +123,7 @@ def cases(seed):
             capsules = caps
         extra = dict(capsules=capsules, world=int(rng2.choice([1, 1, 2, 3])), parts=int(rng2.choice([1, 2, 3])),
                      count=bool(rng2.random() < 0.5))   # half of the cases run the production kernels (no counters)
-        if rng2.random() < 0.12:                    # camera INSIDE the bounding sphere: low orbit, or under the terrain
+        if rng2.random() < p_inside:                # camera INSIDE the bounding sphere: low orbit, or under the terrain
             e = rng2.normal(size=3); e /= np.linalg.norm(e)
             s.eye = tuple(np.asarray(s.center, float) + e * s.radius * rng2.uniform(0.85, 0.9999))
             t = rng2.normal(size=3); t /= np.linalg.norm(t)
