@@ -12,9 +12,9 @@ W, H, spp, dem_h, dem_w, col_shape = bench.WORKLOADS["cfg3"]
 src = synth_ldem(dem_h, dem_w); dem, _ = dem_from_ldem(src, dem_h, dem_w, 1); src.free()
 col = synth_color(*col_shape)
 stars = bench.synth_starmap(8192, 16384)
-for seg in ((2, 4), (1, 1)):
+for seg, S in (((2, 4), 64), ((1, 1), 64), ((2, 4), 1)):
     for bg in (None, stars):
-        scene = named_scene("S1", W, H, spp_per_launch=64)
+        scene = named_scene("S1", W, H, spp_per_launch=S)
         scene.path_seg_min, scene.path_seg_max = seg
         rt = MoonRT(W, H); rt.bind_dem(dem, dem_h, dem_w); rt.bind_color(col, *col_shape)
         rt.apply_scene(scene); rt.set_params(flags=int(os.environ.get("FLAGS", "0")))
@@ -24,5 +24,5 @@ for seg in ((2, 4), (1, 1)):
         for _ in range(3):
             rt.reset(); st = rt.render(1); t.append((st["kernel_ms"], st["primary_ms"], st["paths_ms"]))
         k, p, q = min(t)
-        print(f"path_seg_range {seg}, {'star map 16384x8192' if bg is not None else 'no environment  '}: {k:7.3f} ms (render {p:.3f} + paths {q:.3f})", flush=True)
+        print(f"{S:2d} spp per launch, path_seg_range {seg}, {'star map 16384x8192' if bg is not None else 'no environment  '}: {k:7.3f} ms (render {p:.3f} + paths {q:.3f})", flush=True)
         rt.close()
