@@ -112,6 +112,30 @@ def sun_altitude_at(subsolar_lat, subsolar_lon, lat_deg, lon_deg):          # as
     return float(body_altitude_at_feature(np.asarray(subsolar_lat), np.asarray(subsolar_lon), lat_deg, lon_deg))
 
 
+RENDERER_TO_BODY = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])   # astro.py:20-25
+
+
+def latlon_from_icrf(pos, R_icrf_to_body):      # astro.py:106-113
+    """ICRF position vector -> body-frame (lat_deg, lon_deg)."""
+    b = np.asarray(R_icrf_to_body, float) @ np.asarray(pos, float)
+    return math.degrees(math.asin(b[2] / np.linalg.norm(b))), math.degrees(math.atan2(b[1], b[0]))
+
+
+def rotation_matrix(R_moon, R_equator, moon_ra_deg, moon_dec_deg, q_deg):      # astro.py:116-139
+    """Renderer-body -> view rotation from the body frame (ICRF -> Moon-fixed `R_moon`), the equator-of-date frame
+    `R_equator`, the Moon's apparent (RA, Dec) of date and the roll `q_deg` of 'up' from celestial north towards east:
+    rows of the view basis = (right, line of sight, up).  Pinned by tests/golden/host_astro.json."""
+    ra, dec, q = moon_ra_deg * DEG, moon_dec_deg * DEG, q_deg * DEG
+    sight = np.array([math.cos(dec) * math.cos(ra), math.cos(dec) * math.sin(ra), math.sin(dec)])
+    east = np.array([-math.sin(ra), math.cos(ra), 0.0])
+    north = np.array([-math.sin(dec) * math.cos(ra), -math.sin(dec) * math.sin(ra), math.cos(dec)])
+    up = math.sin(q) * east + math.cos(q) * north
+    up = up / np.linalg.norm(up)
+    right = np.cross(sight, up)
+    right = right / np.linalg.norm(right)
+    return np.vstack([right, sight, up]) @ (np.asarray(R_equator, float) @ np.asarray(R_moon, float).T) @ RENDERER_TO_BODY
+
+
 # ---- Meeus ch. 22: nutation and obliquity (the four largest terms: 0.5" / 0.1") -------------------------------------
 def nutation(T):
     """(dpsi_deg, deps_deg, eps_true_deg, Omega_deg)."""
