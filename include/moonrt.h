@@ -176,6 +176,11 @@ int mrtx_render_part(mrtx_ctx* ctx, int32_t n_blocks, int32_t part, int32_t n_pa
  *            moon_renderer.py:1138, renderer_navigation.py:195-203 */
 int mrtx_read_linear(mrtx_ctx* ctx, float* rgba_out);
 int mrtx_read_rgba8(mrtx_ctx* ctx, uint8_t* out);
+/* rt.save_image(path, bps="Bps16") -- renderer_dialogs.py:1222-1224 (".tiff" is saved with 16 bits per sample): the same
+ * exposure + "Gamma" post-process at 16 bits, W*H*3 uint16 (RGB interleaved), caller-owned.  Both tone-mapped read-backs are
+ * exact: level = round(N * (exposure * mean)^(1/gamma)) decided by comparing with N float32 thresholds
+ * (float)pow((j - 0.5) / N, gamma) built on the host, so they equal the oracle's bytes. */
+int mrtx_read_rgb16(mrtx_ctx* ctx, uint16_t* out);
 int mrtx_read_hits(mrtx_ctx* ctx, float* xyzd_out);
 /* One texel of the hit buffer (16 bytes over PCIe): what rt._get_hit_at(x, y) needs per mouse event
  * (moon_renderer.py:1137-1142) without pulling the 133 MB buffer of a 4K frame after every launch. */

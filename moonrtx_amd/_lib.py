@@ -69,6 +69,7 @@ SIGNATURES = {
     "mrtx_render_part": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(MrtxStats)]),
     "mrtx_read_linear": (C.c_int, [_VP, _VP]),
     "mrtx_read_rgba8": (C.c_int, [_VP, _VP]),
+    "mrtx_read_rgb16": (C.c_int, [_VP, _VP]),
     "mrtx_read_hits": (C.c_int, [_VP, _VP]),
     "mrtx_read_hit": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "mrtx_samples_done": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),

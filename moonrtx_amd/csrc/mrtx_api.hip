@@ -23,7 +23,9 @@ int mrtx_path_waves(bool stats, bool wide, int* out);
 hipError_t mrtx_launch_paths(const FrameC& f, const PathQ& pq, int S, bool stats, int n_waves, hipStream_t st);
 hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t npix, uint32_t ns, hipStream_t st);
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
-                                     float invg, const uint32_t* overlay, hipStream_t st);
+                                     const float* T8, const uint32_t* overlay, hipStream_t st);
+hipError_t mrtx_launch_resolve_rgb16(const float* accum, uint16_t* out, int64_t npix, uint32_t ns, float expo,
+                                     const float* T16, hipStream_t st);
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
                             int tiles_x, int n_tiles, int rank, int world, int slot0, int slots, const int32_t* list, int shift,
                             hipStream_t st);
@@ -68,6 +70,9 @@ struct mrtx_ctx {
     float* accum = nullptr;
     float* hits = nullptr;
     void* scratch = nullptr;  // W*H*16 bytes, resolve target for read-back
+    // "Gamma" post-process tables (tone_table): 256 / 65536 thresholds for the gamma they were built for (0 = not built)
+    float* tone8_dev = nullptr; float tone8_gamma = 0.0f;
+    float* tone16_dev = nullptr; float tone16_gamma = 0.0f;
     float* dem = nullptr; int dem_h = 0, dem_w = 0;   // padded (h+4) x (w+4) copy, always owned
     float* hmip = nullptr; int hm_h = 0, hm_w = 0, hm_shift = 0;       // horizon mip: cells of 8 max-mip cells, dilated by one cell (see horizon_kend)
     float* mip = nullptr; int mip_h = 0, mip_w = 0, mip_shift = 0;   // max-mip of it, cell 2^mip_shift texels (+ one-cell border)
@@ -498,6 +503,8 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->accum) (void)hipFree(c->accum);
     if (c->hits) (void)hipFree(c->hits);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->tone8_dev) (void)hipFree(c->tone8_dev);
+    if (c->tone16_dev) (void)hipFree(c->tone16_dev);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
     if (c->cold_dev) (void)hipFree(c->cold_dev);
     if (c->caps_dev) (void)hipFree(c->caps_dev);
@@ -977,6 +984,22 @@ int mrtx_samples_done(mrtx_ctx* c, uint32_t* out) {
     return MRTX_OK;
 }
 
+// Thresholds of the exact "Gamma" post-process: T[0] = 0 (never read as a threshold),
+// T[j] = (float)pow((j - 0.5) / n, gamma) for j = 1..n, float64 on the host, rounded once; n + 1 entries on the device,
+// rebuilt when tonemap_gamma changes.  Level = #{j : exposure * mean >= T[j]} = round(n * (exposure * mean)^(1/gamma)).
+static int tone_table(mrtx_ctx* c, int n, float** dev, float* built_for) {
+    if (*dev && *built_for == c->prm.tonemap_gamma) return MRTX_OK;
+    std::vector<float> T((size_t)n + 1);
+    const double g = (double)c->prm.tonemap_gamma;
+    T[0] = 0.0f;
+    for (int j = 1; j <= n; j++) T[(size_t)j] = (float)pow(((double)j - 0.5) / (double)n, g);
+    if (!*dev) HIPCHK(c, hipMalloc((void**)dev, T.size() * sizeof(float)));
+    HIPCHK(c, hipMemcpyAsync(*dev, T.data(), T.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // T is a local
+    *built_for = c->prm.tonemap_gamma;
+    return MRTX_OK;
+}
+
 int mrtx_read_linear(mrtx_ctx* c, float* out) {
     if (!c || !out) return MRTX_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -990,9 +1013,23 @@ int mrtx_read_rgba8(mrtx_ctx* c, uint8_t* out) {
     if (!c || !out) return MRTX_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int64_t npix = (int64_t)c->cfg.width * c->cfg.height;
+    const int rc = tone_table(c, 255, &c->tone8_dev, &c->tone8_gamma);
+    if (rc != MRTX_OK) return rc;
     HIPCHK(c, mrtx_launch_resolve_rgba8(c->accum, (uint32_t*)c->scratch, npix, c->blocks_done * c->prm.spp_per_launch,
-                                        c->prm.tonemap_exposure, 1.0f / c->prm.tonemap_gamma, c->overlay, c->stream));
+                                        c->prm.tonemap_exposure, c->tone8_dev, c->overlay, c->stream));
     HIPCHK(c, hipMemcpyAsync(out, c->scratch, (size_t)npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MRTX_OK;
+}
+int mrtx_read_rgb16(mrtx_ctx* c, uint16_t* out) {
+    if (!c || !out) return MRTX_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int64_t npix = (int64_t)c->cfg.width * c->cfg.height;
+    const int rc = tone_table(c, 65535, &c->tone16_dev, &c->tone16_gamma);
+    if (rc != MRTX_OK) return rc;
+    HIPCHK(c, mrtx_launch_resolve_rgb16(c->accum, (uint16_t*)c->scratch, npix, c->blocks_done * c->prm.spp_per_launch,
+                                        c->prm.tonemap_exposure, c->tone16_dev, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->scratch, (size_t)npix * 6, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MRTX_OK;
 }

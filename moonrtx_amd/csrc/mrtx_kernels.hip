@@ -1714,10 +1714,19 @@ __global__ void resolve_linear_kernel(const float4* __restrict__ accum, float4* 
         out[i] = nsamples ? make_float4(a.x / ns, a.y / ns, a.z / ns, a.w / ns) : make_float4(0, 0, 0, 0);
     }
 }
-__device__ __forceinline__ uint32_t tone8(float v, float expo, float invg) {
-    float t = powf(fmaxf(expo * v, 0.0f), invg);
-    t = fminf(t, 1.0f);
-    return (uint32_t)floorf(fmaf(t, 255.0f, 0.5f));
+// "Gamma" post-process, exact: level = number of thresholds T[1..N] (N = 255 or 65535) that are
+// <= x = exposure * mean, with T[j] = (float)pow((j - 0.5) / N, gamma) computed once on the host in float64 -- the level
+// round(N * x^(1/gamma)) without a device transcendental, so the byte the GUI shows is the oracle's byte.  T is
+// non-decreasing; a NaN or negative x compares false everywhere (level 0).  BITS steps of a branch-free bisection.
+template <int BITS>
+__device__ __forceinline__ uint32_t tone_level(float x, const float* T) {
+    uint32_t k = 0;
+#pragma unroll
+    for (int b = BITS - 1; b >= 0; b--) {
+        const uint32_t j = k + (1u << b);
+        k = (x >= T[j]) ? j : k;
+    }
+    return k;
 }
 // D12 "Overlay" post-process (renderer_video.py:15-27, :137-144): a frame-sized RGBA8 texture blended over the
 // tone-mapped 8-bit image with exact alpha compositing, out = round((src*(255-a) + ov*a) / 255)
@@ -1726,17 +1735,37 @@ __device__ __forceinline__ uint32_t blend8(uint32_t src, uint32_t ov, uint32_t a
     return (src * (255u - a) + ov * a + 127u) / 255u;
 }
 __global__ void resolve_rgba8_kernel(const float4* __restrict__ accum, uint32_t* __restrict__ out, int64_t n,
-                                     uint32_t nsamples, float expo, float invg, const uint32_t* __restrict__ overlay) {
+                                     uint32_t nsamples, float expo, const float* __restrict__ T8,
+                                     const uint32_t* __restrict__ overlay) {
+    __shared__ float T[256];
+    T[threadIdx.x & 255] = T8[threadIdx.x & 255];       // blockDim.x == 256
+    __syncthreads();
     const float ns = (float)nsamples;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 a = accum[i];
         uint32_t r = 0, g = 0, b = 0;
-        if (nsamples) { r = tone8(a.x / ns, expo, invg); g = tone8(a.y / ns, expo, invg); b = tone8(a.z / ns, expo, invg); }
+        if (nsamples) {
+            r = tone_level<8>(expo * (a.x / ns), T); g = tone_level<8>(expo * (a.y / ns), T); b = tone_level<8>(expo * (a.z / ns), T);
+        }
         if (overlay) {
             const uint32_t o = overlay[i], al = o >> 24;
             r = blend8(r, o & 255u, al); g = blend8(g, (o >> 8) & 255u, al); b = blend8(b, (o >> 16) & 255u, al);
         }
         out[i] = 0xFF000000u | r | (g << 8) | (b << 16);
+    }
+}
+// save_image(..., bps="Bps16") (renderer_dialogs.py:1222-1224): the same post-process at 16 bits per sample, RGB interleaved;
+// T16 has 65536 entries (256 KB, L2 resident); no overlay at 16 bits (the reference composites video frames at 8 bits only).
+__global__ void resolve_rgb16_kernel(const float4* __restrict__ accum, uint16_t* __restrict__ out, int64_t n,
+                                     uint32_t nsamples, float expo, const float* __restrict__ T16) {
+    const float ns = (float)nsamples;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = accum[i];
+        uint32_t r = 0, g = 0, b = 0;
+        if (nsamples) {
+            r = tone_level<16>(expo * (a.x / ns), T16); g = tone_level<16>(expo * (a.y / ns), T16); b = tone_level<16>(expo * (a.z / ns), T16);
+        }
+        out[3 * i] = (uint16_t)r; out[3 * i + 1] = (uint16_t)g; out[3 * i + 2] = (uint16_t)b;
     }
 }
 
@@ -2020,23 +2049,23 @@ __global__ void mip_build_kernel(const float* __restrict__ dem_padded, int h, in
 // themselves dilated by the two-texel tap border).  (hh) x (hw) floats, a few thousand cells.
 __global__ void hmip_build_kernel(const float* __restrict__ mip, int mh, int mw, int shift, float* __restrict__ out,
                                   int hh, int hw, int hshift, int h, int w) {
-    const int mp = mw + 2, Cc = 1 << hshift, C = 1 << shift;
+    const int mp = mw + 2, Cc = 1 << hshift;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < hh * hw; t += gridDim.x * blockDim.x) {
         const int i = t / hw, j = t % hw;
         const int r0 = max(Cc * i - Cc, 0), r1 = min(Cc * i + 2 * Cc - 1, h - 1);
         const int c0 = Cc * j - Cc, c1 = Cc * j + 2 * Cc - 1;
         float m = 0.0f;
+        // fine cells by INDEX, per unwrapped piece of the column range: stepping texel columns by C across the -180/+180
+        // seam skips the last, partial fine cell mw - 1 whenever w is not a multiple of C (round-2 advisor finding)
+        int a0 = 0, a1 = mw - 1, b0 = 1, b1 = 0;        // up to two inclusive fine-cell ranges; the second one empty
+        if (c1 - c0 + 1 < w) {                           // else: the dilated range wraps around the whole map
+            if (c0 < 0)       { a0 = (c0 + w) >> shift; a1 = mw - 1; b0 = 0; b1 = c1 >> shift; }
+            else if (c1 >= w) { a0 = c0 >> shift; a1 = mw - 1; b0 = 0; b1 = (c1 - w) >> shift; }
+            else              { a0 = c0 >> shift; a1 = c1 >> shift; }
+        }
         for (int fi = r0 >> shift; fi <= (r1 >> shift); fi++) {
-            if (c1 - c0 + 1 >= w) {                      // the dilated range wraps around the whole map
-                for (int fj = 0; fj < mw; fj++) m = fmaxf(m, mip[(fi + 1) * mp + fj + 1]);
-            } else {
-                for (int c = c0;; c += C) {
-                    const int cc = min(c, c1);
-                    int cw = cc % w; if (cw < 0) cw += w;
-                    m = fmaxf(m, mip[(fi + 1) * mp + (cw >> shift) + 1]);
-                    if (cc == c1) break;
-                }
-            }
+            for (int fj = a0; fj <= a1; fj++) m = fmaxf(m, mip[(fi + 1) * mp + fj + 1]);
+            for (int fj = b0; fj <= b1; fj++) m = fmaxf(m, mip[(fi + 1) * mp + fj + 1]);
         }
         out[t] = m;
     }
@@ -2199,9 +2228,15 @@ hipError_t mrtx_launch_resolve_linear(const float* accum, float* out, int64_t np
     return hipGetLastError();
 }
 hipError_t mrtx_launch_resolve_rgba8(const float* accum, uint32_t* out, int64_t npix, uint32_t ns, float expo,
-                                     float invg, const uint32_t* overlay, hipStream_t st) {
+                                     const float* T8, const uint32_t* overlay, hipStream_t st) {
     hipLaunchKernelGGL(mrtx::resolve_rgba8_kernel, dim3(grid_for(npix)), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(accum), out, npix, ns, expo, invg, overlay);
+                       reinterpret_cast<const float4*>(accum), out, npix, ns, expo, T8, overlay);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_resolve_rgb16(const float* accum, uint16_t* out, int64_t npix, uint32_t ns, float expo,
+                                     const float* T16, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::resolve_rgb16_kernel, dim3(grid_for(npix)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(accum), out, npix, ns, expo, T16);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,

@@ -222,6 +222,12 @@ class MoonRT:
         self._check(self._lib.mrtx_read_rgba8(self._ctx, out.ctypes.data), "mrtx_read_rgba8")
         return out
 
+    def read_rgb16(self):
+        """The tone-mapped frame at 16 bits per sample, (H, W, 3) uint16 -- save_image(bps="Bps16")."""
+        out = np.empty((self.height, self.width, 3), np.uint16)
+        self._check(self._lib.mrtx_read_rgb16(self._ctx, out.ctypes.data), "mrtx_read_rgb16")
+        return out
+
     def read_hit(self, x, y):
         """One texel of the hit buffer: (hx, hy, hz, hd), hd <= 0 == miss."""
         out = (C.c_float * 4)()

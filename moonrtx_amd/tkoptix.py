@@ -532,11 +532,8 @@ class TkOptiX:
         bps = getattr(bps, "name", bps)
         with self._padlock:
             if str(bps) == "Bps16":
-                lin = self._rt.read_linear()[..., :3]
-                g = 1.0 / float(self._floats.get("tonemap_gamma", 2.2))
-                e = float(self._floats.get("tonemap_exposure", 0.9))
-                img = np.clip(np.power(np.maximum(e * lin, 0.0), g), 0.0, 1.0)
-                arr = np.floor(img * 65535.0 + 0.5).astype(np.uint16)
+                self._push_params(self._cycle_plan()[0])      # exposure / gamma as they stand now
+                arr = self._rt.read_rgb16()                   # exact 16-bit "Gamma" post-process on the device
                 ext = str(file_name).lower().rsplit(".", 1)[-1]
                 if ext in ("tif", "tiff"):
                     write_tiff16(file_name, arr)

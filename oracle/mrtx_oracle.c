@@ -821,6 +821,54 @@ void orc_resolve_linear(const float* accum, int64_t npix, uint32_t n_samples, fl
     for (i = 0; i < 4 * npix; i++) out[i] = n_samples ? accum[i] / n : 0.0f;
 }
 
+/* "Gamma" post-process (add_postproc("Gamma") with tonemap_exposure / tonemap_gamma, moon_renderer.py:598-600) -> the
+ * 8-bit image the GUI shows and save_image writes (renderer_dialogs.py:1222-1224), or 16 bits per sample.
+ * Spec: x = exposure * (sum / n) in float32; level = the number of thresholds
+ * T[j] = (float)pow((j - 0.5) / N, gamma), j = 1..N (float64 pow, rounded once), that are <= x -- i.e.
+ * round(N * x^(1/gamma)) clamped to [0, N], decided by comparisons only.  N = 255 or 65535. */
+void orc_tone_table(double gamma, int32_t n, float* T) {
+    int32_t j;
+    T[0] = 0.0f;
+    for (j = 1; j <= n; j++) T[j] = (float)pow(((double)j - 0.5) / (double)n, gamma);
+}
+static uint32_t tone_level(float x, const float* T, int32_t n) {
+    /* upper bound: first j in [1, n+1) with x < T[j]; level = j - 1.  NaN compares false -> level 0. */
+    int32_t lo = 1, hi = n + 1;
+    if (!(x >= T[1])) return 0;
+    while (lo < hi) {
+        int32_t mid = lo + (hi - lo) / 2;
+        if (x >= T[mid]) lo = mid + 1; else hi = mid;
+    }
+    return (uint32_t)(lo - 1);
+}
+/* D12 compositing (renderer_video.py:15-27, :137-144): out = round((src*(255-a) + ov*a) / 255) per channel */
+static uint32_t blend8(uint32_t src, uint32_t ov, uint32_t a) { return (src * (255u - a) + ov * a + 127u) / 255u; }
+void orc_resolve_rgba8(const float* accum, int64_t npix, uint32_t n_samples, float exposure, float gamma,
+                       const uint8_t* overlay, uint8_t* out) {
+    float T[256];
+    int64_t i; int k;
+    const float n = (float)n_samples;
+    orc_tone_table((double)gamma, 255, T);
+    for (i = 0; i < npix; i++) {
+        for (k = 0; k < 3; k++) {
+            uint32_t v = n_samples ? tone_level(exposure * (accum[4 * i + k] / n), T, 255) : 0u;
+            if (overlay) v = blend8(v, overlay[4 * i + k], overlay[4 * i + 3]);
+            out[4 * i + k] = (uint8_t)v;
+        }
+        out[4 * i + 3] = 255;
+    }
+}
+void orc_resolve_rgb16(const float* accum, int64_t npix, uint32_t n_samples, float exposure, float gamma, uint16_t* out) {
+    float* T = (float*)malloc(65536 * sizeof(float));
+    int64_t i; int k;
+    const float n = (float)n_samples;
+    orc_tone_table((double)gamma, 65535, T);
+    for (i = 0; i < npix; i++)
+        for (k = 0; k < 3; k++)
+            out[3 * i + k] = (uint16_t)(n_samples ? tone_level(exposure * (accum[4 * i + k] / n), T, 65535) : 0u);
+    free(T);
+}
+
 /* data_loader.py:166-247 restated: int16 LDEM (h*d, w*d) -> float32 (h, w) displacement factors.
  * Stage 1 (axis 4): exact integer sum of d int16 as float32, / d.  Stage 2 (axis 2): sequential
  * float32 sum over the d rows, / d.  Then * (0.5/1737400), + 1, / max. */

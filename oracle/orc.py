@@ -73,6 +73,12 @@ def lib():
                                  C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_resolve_linear.restype = None
         L.orc_resolve_linear.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p]
+        L.orc_tone_table.restype = None
+        L.orc_tone_table.argtypes = [C.c_double, C.c_int32, C.c_void_p]
+        L.orc_resolve_rgba8.restype = None
+        L.orc_resolve_rgba8.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_resolve_rgb16.restype = None
+        L.orc_resolve_rgb16.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
         L.orc_frame_floats.restype = None
         L.orc_frame_floats.argtypes = [C.POINTER(OrcScene), C.c_void_p]
         L.orc_dem_from_ldem.restype = C.c_float
@@ -114,6 +120,13 @@ def latlon(a, b, c):
         L.orc_latlon(float(a[i]), float(b[i]), float(c[i]), C.byref(la), C.byref(lo))
         lat[i] = la.value; lon[i] = lo.value
     return lat, lon
+
+
+def tone_table(gamma, n):
+    """Thresholds T[0..n] of the spec's "Gamma" post-process (T[0] = 0 is not a threshold)."""
+    T = np.empty(n + 1, np.float32)
+    lib().orc_tone_table(float(gamma), int(n), T.ctypes.data)
+    return T
 
 
 def dem_bilinear(dem, lat_rad, lon_rad):
@@ -196,6 +209,20 @@ class Oracle:
         out = np.empty_like(self.accum)
         self.L.orc_resolve_linear(self.accum.ctypes.data, self.s.width * self.s.height,
                                   self.blocks_done * self.s.spp_per_block, out.ctypes.data)
+        return out
+
+    def rgba8(self, exposure=0.9, gamma=2.2, overlay=None):
+        """The tone-mapped 8-bit frame (exposure + "Gamma" post-process, optional RGBA8 overlay composited on top)."""
+        out = np.empty((self.s.height, self.s.width, 4), np.uint8)
+        ov = None if overlay is None else np.ascontiguousarray(overlay, np.uint8)
+        self.L.orc_resolve_rgba8(self.accum.ctypes.data, self.s.width * self.s.height, self.blocks_done * self.s.spp_per_block,
+                                 exposure, gamma, None if ov is None else ov.ctypes.data, out.ctypes.data)
+        return out
+
+    def rgb16(self, exposure=0.9, gamma=2.2):
+        out = np.empty((self.s.height, self.s.width, 3), np.uint16)
+        self.L.orc_resolve_rgb16(self.accum.ctypes.data, self.s.width * self.s.height, self.blocks_done * self.s.spp_per_block,
+                                 exposure, gamma, out.ctypes.data)
         return out
 
     def frame_floats(self):

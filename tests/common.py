@@ -28,10 +28,12 @@ def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, ti
         rt.close()
 
 
-def render_oracle(scene, dem, color=None, bg=None, blocks=(1,), region=None, capsules=None):
+def render_oracle(scene, dem, color=None, bg=None, blocks=(1,), region=None, capsules=None, rgba8=False):
     o = orc.Oracle(scene, dem, color, bg, capsules)
     for nb in blocks:
         st = o.render(nb, region)
+    if rgba8:       # + the tone-mapped 8-bit frame (exposure / gamma of the scene), what render_hip returns fourth
+        return o.linear(), o.hits.copy(), st, o.rgba8(scene.exposure, scene.gamma)
     return o.linear(), o.hits.copy(), st
 
 

@@ -84,13 +84,14 @@ def random_scene(rng):
 
 
 
-def cases(seed):
+def cases(seed, exotic=None):
     """Endless generator of (description, dem, colour, background, scene, flags, tile, blocks, extra); `extra` =
     dict(capsules, world, parts) drawn from a second stream, so case k of a seed keeps its scene as options are added."""
     rng = np.random.default_rng(seed)
     case = 0
     import os
-    exotic = bool(os.environ.get("FUZZ_EXOTIC"))   # campaign option: the rare combinations (camera inside the shell of overlay
+    if exotic is None:
+        exotic = bool(os.environ.get("FUZZ_EXOTIC"))   # campaign option: the rare combinations (camera inside the shell of overlay
     p_bg, p_caps, p_inside = (0.7, 0.7, 0.5) if exotic else (0.3, 0.25, 0.12)   # tubes, environment map, paths) in most cases
     while True:
         dem = random_dem(rng)
@@ -130,6 +131,8 @@ def cases(seed):
             s.target = tuple(np.asarray(s.eye) + t * s.radius)
             s.up = tuple(np.cross(t, [0.37, 0.11, 0.92])); s.vfov_deg = float(rng2.uniform(10, 120))
         extra["inwave"] = bool(rng2.random() < 0.35)   # D6 inside the render wave instead of behind the path queue
+        if rng2.random() < 0.3:                     # the "Gamma" post-process away from its defaults (round 3: the 8-bit image is compared too)
+            s.gamma = float(rng2.choice([0.5, 1.0, 1.8, 3.3, 5.0])); s.exposure = float(rng2.uniform(0.3, 3.0))
         desc = (f"seed {seed} case {case}: dem {dem.shape} frame {s.width}x{s.height} S={s.spp_per_launch} "
                 f"seg=({s.path_seg_min},{s.path_seg_max}) fov {s.vfov_deg:.2f} step {s.marching_step:.2g} flags {flags} tile {tile} "
                 f"blocks {blocks} col {None if col is None else col.shape[:2]} bg {None if bg is None else bg.shape[:2]} "
@@ -181,15 +184,16 @@ def check_case(c):
     if extra.get("inwave"):
         flags |= _lib.F_INWAVE_PATHS
     caps = extra["capsules"]
-    lin_o, hits_o, st_o = render_oracle(s, dem, col, bg, blocks=blocks, capsules=caps)
+    lin_o, hits_o, st_o, img_o = render_oracle(s, dem, col, bg, blocks=blocks, capsules=caps, rgba8=True)
     if extra["world"] > 1:
         lin_h, hits_h = render_sharded(s, dem, col, bg, blocks, tile, flags, caps, extra["world"], extra["parts"])
         assert_bit_equal(lin_h, lin_o, desc + ": sharded radiance")
         assert_bit_equal(hits_h, hits_o, desc + ": sharded hits")
         return st_o
-    lin_h, hits_h, st_h, _ = render_hip(s, dem, col, bg, blocks=blocks, tile=tile, flags=flags, capsules=caps)
+    lin_h, hits_h, st_h, img_h = render_hip(s, dem, col, bg, blocks=blocks, tile=tile, flags=flags, capsules=caps)
     assert_bit_equal(lin_h, lin_o, desc + ": radiance")
     assert_bit_equal(hits_h, hits_o, desc + ": hits")
+    assert np.array_equal(img_h, img_o), desc + ": tone-mapped RGBA8 image"
     if len(blocks) == 1 and (flags & _lib.F_COUNT_STATS):
         got = {k: st_h[k] for k in STAT_KEYS}
         want = {k: st_o[k] for k in STAT_KEYS}

@@ -239,12 +239,11 @@ def test_save_image_16_bits_is_really_16_bits(tmp_path):
     import struct
     from PIL import Image
     be = RecordingBackend(16, 8)
-    lin = np.zeros((8, 16, 4), np.float32)
-    lin[..., 0] = np.linspace(0.0, 1.0, 16)[None, :]; lin[..., 1] = 0.25; lin[..., 2] = 1.0e-3
-    be.read_linear = lambda: lin
+    want = np.zeros((8, 16, 3), np.uint16)          # the backend's 16-bit frame (mrtx_read_rgb16; values checked on the GPU
+    want[..., 0] = np.linspace(0, 65535, 16).astype(np.uint16)[None, :]; want[..., 1] = 0x1234; want[..., 2] = 7   # against the oracle)
+    be.read_rgb16 = lambda: want
     rt = TkOptiX(width=16, height=8, backend=be)
     rt.set_float("tonemap_exposure", 0.9); rt.set_float("tonemap_gamma", 2.2)
-    want = np.floor(np.clip((0.9 * lin[..., :3]) ** (1 / 2.2), 0, 1) * 65535.0 + 0.5).astype(np.uint16)
     p = tmp_path / "frame.tiff"
     rt.save_image(str(p), bps="Bps16")
     raw = p.read_bytes()
@@ -255,6 +254,7 @@ def test_save_image_16_bits_is_really_16_bits(tmp_path):
     assert struct.unpack_from("<HHH", raw, tags[258][3]) == (16, 16, 16)
     got = np.frombuffer(raw, "<u2", count=8 * 16 * 3, offset=tags[273][3]).reshape(8, 16, 3)
     assert np.array_equal(got, want) and len(np.unique(got[..., 0])) == 16          # 16 distinct levels: not 8-bit data
+    assert be.last("set_params")[2]["tonemap_gamma"] == 2.2                          # the post-process parameters were pushed first
     assert Image.open(str(p)).size == (16, 8)
     q = tmp_path / "frame.png"
     rt.save_image(str(q), bps="Bps16")

@@ -160,3 +160,6 @@ def test_cfg4_one_rank_of_eight_at_full_size(native_lib):
     lin1, hits1 = rt.read_linear(), rt.read_hits()
     rt.close()
     oracle_crops(s, dem, lin1, hits1, [(tx0 * 32, ty0 * 32, 32, 32)])
+    # ... and the same owned tile of the (2, 4) frame rendered above through the path queue (first block of 64 spp)
+    s.path_seg_min, s.path_seg_max = 2, 4
+    oracle_crops(s, dem, a, ha, [(tx0 * 32, ty0 * 32, 32, 32)])

@@ -108,6 +108,80 @@ def test_crop_of_the_full_frame_matches_the_oracle(inputs):
     assert orc.quad_out_of_range() == 0
 
 
+@pytest.fixture(scope="module")
+def host_inputs(inputs):
+    dem_b, col_b, _ = inputs
+    return dem_b.download(np.float32, (DEM_H, DEM_W)), col_b.download(np.uint8, (COL_H, COL_W, 4))
+
+
+# 64x48 crops of the cfg3 frame: across the terminator, the lit limb with sky beside it, the disc centre, the dark limb
+HEADLINE_CROPS = ((1500, 1000), (2860, 1060), (1888, 1056), (930, 1300))
+
+
+def headline_scene():
+    s = named_scene("S1", W, H, spp_per_launch=64)
+    s.path_seg_min, s.path_seg_max = 2, 4                 # moon_renderer.py:583
+    return s
+
+
+def check_crops(rt, s, host_inputs, bg=None, what=""):
+    from oracle import orc
+    dem, col = host_inputs
+    lin = rt.read_linear(); hits = rt.read_hits(); img = rt.read_rgba8(); img16 = rt.read_rgb16()
+    o = orc.Oracle(s, dem, col, bg)
+    lit = 0
+    for (x0, y0) in HEADLINE_CROPS:
+        reg = (x0, y0, x0 + 64, y0 + 48)
+        o.reset()
+        o.render(1, reg)
+        sl = (slice(y0, y0 + 48), slice(x0, x0 + 64))
+        assert_bit_equal(lin[sl], o.linear()[sl], f"{what} radiance, crop at {x0},{y0}")
+        assert_bit_equal(hits[sl], o.hits[sl], f"{what} hits, crop at {x0},{y0}")
+        assert np.array_equal(img[sl], o.rgba8(s.exposure, s.gamma)[sl]), f"{what} RGBA8, crop at {x0},{y0}"
+        assert np.array_equal(img16[sl], o.rgb16(s.exposure, s.gamma)[sl]), f"{what} RGB16, crop at {x0},{y0}"
+        lit += int((lin[sl][..., :3].max(-1) > 0.02).sum())
+    assert lit > 3000 and orc.quad_out_of_range() == 0
+    return lin
+
+
+def test_headline_frame_crops_match_the_oracle(inputs, host_inputs, monkeypatch):
+    """THE workload bench.py times -- cfg3, colour map, the reference's path_seg_range (2, 4) (moon_renderer.py:583), 64 spp,
+    production kernels (flags = 0: no counters), WIDE addressing, record queue + path_kernel + resolve, default scheduling
+    (no MOONRT_* test override) -- against the oracle on four crops: linear radiance, hit buffer, the 8-bit image the GUI
+    shows and the 16-bit save_image data, all bit for bit."""
+    monkeypatch.delenv("MOONRT_PATH_QUEUE_MIN", raising=False)
+    monkeypatch.delenv("MOONRT_DEFAULT_FLAGS", raising=False)
+    s = headline_scene()
+    rt = make(inputs, 64)
+    rt.apply_scene(s)
+    rt.set_params(flags=0)
+    st = rt.render(1)
+    assert st["launches"] == 3 and st["paths_ms"] > 0.0        # render_kernel<MODE 2> + path_kernel + resolve_paths_kernel
+    check_crops(rt, s, host_inputs, what="headline")
+    rt.close()
+
+
+def test_headline_frame_with_the_star_map_crops_match_the_oracle(inputs, host_inputs, monkeypatch):
+    """The same frame with the reference's default environment (a 16384x8192 star map, moon_renderer.py:604-607; synthetic
+    here): sky tiles rendered by render_kernel<MODE 3>, escaping continuation rays look their texel up (PS_ESCAPED)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    monkeypatch.delenv("MOONRT_PATH_QUEUE_MIN", raising=False)
+    monkeypatch.delenv("MOONRT_DEFAULT_FLAGS", raising=False)
+    stars = bench.synth_starmap(8192, 16384)
+    s = headline_scene()
+    rt = make(inputs, 64)
+    rt.upload_background(stars)
+    rt.apply_scene(s)
+    rt.set_params(flags=0)
+    st = rt.render(1)
+    assert st["launches"] == 4                                 # + the sky-only tiles' own launch
+    lin = check_crops(rt, s, host_inputs, bg=stars, what="star map")
+    assert lin[:40, :, :3].max() > 0.0                         # the sky is not black any more
+    rt.close()
+
+
 def test_production_kernels_equal_the_counting_kernels_at_full_size(inputs):
     """The kernels bench.py times carry no counters (flags = 0): separate template instantiations with their own
     register allocation.  At full size they must reproduce the counting kernels' frame -- which the crop test above pins

@@ -22,3 +22,12 @@ def test_random_cases_match_the_oracle(native_lib):
         total += fuzz_cases.check_case(c)["primary_hits"]
     total += fuzz_cases.check_case(next(itertools.islice(fuzz_cases.cases(430), 11, 12)))["primary_hits"]
     assert total > 100000
+
+
+def test_exotic_cases_match_the_oracle(native_lib):
+    """The rare combinations of the round-2 campaign (FUZZ_EXOTIC: camera inside the shell of overlay tubes in half of the
+    cases, environment map and tubes in 70 %, paths in 85 %): the first 30 cases of exotic seed 13, in the driver-run suite."""
+    total = 0
+    for c in itertools.islice(fuzz_cases.cases(13, exotic=True), 30):
+        total += fuzz_cases.check_case(c)["primary_rays"]
+    assert total > 100000

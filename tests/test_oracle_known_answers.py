@@ -190,3 +190,42 @@ def test_multi_bounce_paths_behave_physically(oracle_lib):
     # (2,2): exactly one continuation ray per primary hit, no roulette
     _, st22 = render(0.3, (2, 2))
     assert st22["bounce_rays"] == st22["primary_hits"]
+
+
+def test_tone_map_spec_levels_and_thresholds(oracle_lib):
+    """level = #{j : x >= (float)pow((j - 0.5) / N, gamma)} -- the rounded (exposure * mean)^(1/gamma),
+    decided by comparisons; a value ON a threshold gets the upper level, the float just below it the lower one."""
+    for gamma in (0.5, 1.0, 2.2, 5.0):
+        for n in (255, 65535):
+            g32 = float(np.float32(gamma))          # tonemap_gamma is a float32 parameter (set_float); the table is built from it
+            T = orc.tone_table(g32, n)
+            assert T.shape == (n + 1,) and T[0] == 0.0 and np.all(np.diff(T[1:]) >= 0) and T[n] < 1.0
+            assert np.array_equal(T[1:], np.power((np.arange(1, n + 1) - 0.5) / n, g32).astype(np.float32))
+            js = np.unique(np.concatenate([np.arange(1, 8), np.arange(n - 6, n + 1), np.linspace(1, n, 50).astype(int)]))
+            on = T[js]
+            below = np.nextafter(on, np.float32(-1))
+            x = np.concatenate([on, below, [0.0, -1.0, np.nan, 1.0, 7.5, np.inf]]).astype(np.float32)
+            acc = np.zeros((x.size, 4), np.float32)
+            acc[:, 0] = x * 4            # accumulated over 4 samples with exposure 1: x * 4 / 4 == x exactly
+            if n == 255:
+                out = np.empty((x.size, 4), np.uint8)
+                oracle_lib.orc_resolve_rgba8(acc.ctypes.data, x.size, 4, 1.0, gamma, None, out.ctypes.data)
+                lv = out[:, 0].astype(int)
+                assert (out[:, 3] == 255).all() and (out[:, 1] == 0).all()
+            else:
+                out = np.empty((x.size, 3), np.uint16)
+                oracle_lib.orc_resolve_rgb16(acc.ctypes.data, x.size, 4, 1.0, gamma, out.ctypes.data)
+                lv = out[:, 0].astype(int)
+            k = len(js)
+            want_on = np.searchsorted(T[1:], on, side="right")          # ties between equal thresholds count all of them
+            assert np.array_equal(lv[:k], want_on) and np.all(lv[:k] >= js)
+            assert np.array_equal(lv[k:2 * k], np.searchsorted(T[1:], below, side="right")) and np.all(lv[k:2 * k] < js)
+            assert lv[2 * k:].tolist() == [0, 0, 0, n, n, n]
+    # against the textbook formula in float64: equal except within rounding of a level boundary
+    rng = np.random.default_rng(9)
+    x = rng.random(20000).astype(np.float32) * np.float32(1.3)
+    acc = np.zeros((x.size, 4), np.float32); acc[:, 0] = x
+    out = np.empty((x.size, 4), np.uint8)
+    oracle_lib.orc_resolve_rgba8(acc.ctypes.data, x.size, 1, 0.9, 2.2, None, out.ctypes.data)
+    ref = np.floor(np.clip((np.float32(0.9) * x).astype(np.float64) ** (1 / 2.2), 0, 1) * 255 + 0.5).astype(int)
+    assert np.abs(out[:, 0].astype(int) - ref).max() <= 1 and (out[:, 0] != ref).mean() < 1e-4
