@@ -226,13 +226,16 @@ def main():
         torch.cuda.synchronize()
 
     def timed(n):
-        acc = {"kernel_ms": 0.0, "primary_ms": 0.0, "paths_ms": 0.0}
+        acc = {"kernel_ms": 0.0, "primary_ms": 0.0, "paths_ms": 0.0, "pack_ms": 0.0, "gather_wait_ms": 0.0, "unpack_ms": 0.0}
         barrier()
         t = time.perf_counter()
         for _ in range(n):
             st_ = step()
-            for k in acc:
+            for k in ("kernel_ms", "primary_ms", "paths_ms"):
                 acc[k] += st_[k]
+            for k, v in (getattr(gather, "last_timing", None) or {}).items():
+                if k in acc:
+                    acc[k] += v
         barrier()
         el = time.perf_counter() - t
         return el, {k: v / max(1, n) for k, v in acc.items()}
@@ -247,7 +250,8 @@ def main():
 
     # whole-job numbers: max time over ranks, counts summed over ranks
     red_dev = "cpu" if backend == "gloo" else "cuda"
-    mine = torch.tensor([elapsed, km["kernel_ms"], km["primary_ms"], km["paths_ms"]], dtype=torch.float64, device=red_dev)
+    mine = torch.tensor([elapsed, km["kernel_ms"], km["primary_ms"], km["paths_ms"], km["pack_ms"], km["gather_wait_ms"], km["unpack_ms"]],
+                        dtype=torch.float64, device=red_dev)
     tt = mine.clone()
     cnt = torch.tensor([counted[k] for k in COUNT_KEYS], dtype=torch.int64, device=red_dev)
     per_rank = None
@@ -257,7 +261,7 @@ def main():
         per_rank = [[round(float(v), 4) for v in t_] for t_ in allr]
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.SUM)
-    elapsed, kernel_ms, primary_ms, paths_ms = (float(v) for v in tt)
+    elapsed, kernel_ms, primary_ms, paths_ms = (float(v) for v in tt[:4])
     frame = dict(zip(COUNT_KEYS, (int(v) for v in cnt)))
 
     # Beside the headline: the direct-light-only frame (path_seg_range (1, 1)).  Its counters are also what
@@ -361,16 +365,39 @@ def main():
             else:
                 prof_note = (f"profiles/traffic_latest.json is stale (taken with kernel sources {cand.get('source_hash')}, "
                              f"path_seg {cand.get('path_seg')}; these are {source_hash()}, {list(seg)})")
-        pk = None
-        if prof:
+        def prof_entry(kernel):
+            """Counters of exactly this instantiation (profiles written before round 3 carry no full name: base name only)."""
+            if not prof:
+                return None
+            base = kernel.split("<")[0]
             for name, v in prof["kernels"].items():
-                if name.split("<")[0] == dom.split("<")[0]:
-                    pk = v
+                full = v.get("name")
+                if name == base and (full is None or kernel.replace(" ", "") in full.replace("void mrtx::", "").replace(" ", "")):
+                    return v
+            return None
+
+        def measured(v):
+            if v is None:
+                return None
+            util = v["hbm_bytes"] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if v.get("hbm_bytes") and v.get("avg_ms") else None
+            lim = None
+            if util is not None:
+                lim = "hbm" if util >= 0.6 else ("valu+latency" if (v.get("valu_issue_frac") or 0) >= 0.3 else "latency")
+            return {"hbm_bytes": int(v["hbm_bytes"]) if v.get("hbm_bytes") else None, "hbm_utilisation": None if util is None else round(util, 4),
+                    "valu_issue_frac": v.get("valu_issue_frac"), "lanes_per_valu_inst": v.get("lanes_per_valu"), "l2_hit": v.get("l2_hit"),
+                    "profile_kernel_ms": v.get("avg_ms"), "limited_by": lim}
+
+        pk = prof_entry(dom)
+        for kname, kv in kernels.items():        # what the counters say, kernel by kernel (the path stage is named by its first kernel)
+            kv["measured"] = measured(prof_entry(kname.split(" + ")[0]))
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None if pk is None else int(pk["hbm_bytes"]),
                 "kernel": dom, "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": int(dom_bytes),
-                "limiter": "VALU issue + dependent-load latency (not HBM bandwidth): see valu_issue_frac / hbm_utilisation",
+                "limited_by": (measured(pk) or {}).get("limited_by"),
+                "limiter": "`bound` names the roofline the fraction is priced against (the HBM read roofline BASELINE.json asks for); what the PMC "
+                           "counters say limits each kernel is `limited_by` (here and per kernel under `kernels`): hbm = measured HBM traffic >= 0.6 "
+                           "of peak, valu+latency = VALU issue >= 0.3 with HBM far from its peak (dependent-load rounds x the waves a SIMD holds)",
                 "valu_issue_frac": None if pk is None else pk.get("valu_issue_frac"),
                 "hbm_utilisation": None if pk is None else round(pk["hbm_bytes"] / (pk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "lanes_per_valu_inst": None if pk is None else pk.get("lanes_per_valu"),
@@ -400,21 +427,27 @@ def main():
                                    + f", scene {args.scene}" + (f" zoomed on the terminator (vfov {args.zoom} deg)" if args.zoom > 0 else "")
                                    + f", path_seg_range {seg}"
                                    + (" = the reference's setting (moon_renderer.py:583)" if seg == (2, 4) else ""),
-                       "parallelism": f"image tiles 32x32 dealt round-robin (2-D lattice) over {world} GPU(s), active tiles gathered to rank 0"
-                                      + (", RCCL gather of float4 radiance+hits to rank 0" if world > 1 else ""),
+                       "parallelism": f"image tiles 32x32 dealt round-robin (2-D lattice) over {world} GPU(s)"
+                                      + ("" if world == 1 else ", packed float4 radiance + hit tiles of the active tiles gathered to rank 0 by torch.distributed.gather over "
+                                         + ("RCCL (xGMI)" if backend == "nccl" else f"{backend} (staged through host memory: a rehearsal, not the production transport)")
+                                         + f" in {int((getattr(gather, 'last_timing', None) or {}).get('parts', 1))} part(s), all but the last overlapped with rendering"),
                        "march": "step 5e-3, eps 3e-4, scene_epsilon 1e-4, 1 light sample + shadow ray per path vertex, "
                                 f"path_seg_range {seg}" + (" (direct light only)" if seg[1] <= 1 else
                                                           (", paths continued by persistent waves behind a record queue" if queue else
                                                            ", paths continued inside the render wave"))},
             "distributed": {"backend": backend, "world_size": dist_world,
-                            "per_rank_[wall_s, kernel_ms, primary_ms, paths_ms]": per_rank,
-                            "gather_bytes_per_rank": getattr(gather, "last_bytes", None)},
+                            "per_rank_[wall_s, kernel_ms, primary_ms, paths_ms, pack_ms, gather_wait_ms, unpack_ms]": per_rank,
+                            "gather_bytes_per_rank": getattr(gather, "last_bytes", None),
+                            "note": "per step, means over the timed steps: kernel_ms = HIP-event time of this rank's kernels; pack_ms = "
+                                    "mrtx_pack_part calls; gather_wait_ms = what of the exchange the rendering did not hide (wait for the "
+                                    "asynchronous gathers + device synchronise); unpack_ms = mrtx_unpack_all on rank 0"},
             "kernel_ms": round(kernel_ms, 3), "primary_ms": round(primary_ms, 3), "paths_ms": round(paths_ms, 3),
             "frame_counts": frame,
             "bytes_per_ray": round(algorithmic_bytes(frame, W, H) / rays, 2),
             "bytes_per_ray_nominal": round(algorithmic_bytes(frame, W, H, nominal=True) / rays, 2),
             "roofline": roof,
             "inputs_s": round(t_inputs, 2),
+            "hip_runtime": _lib.hip_runtimes_loaded(),     # the ONE libamdhip64 this process runs on (moonrtx_amd/_lib.py)
         }
         if also is not None:
             out["also"] = also

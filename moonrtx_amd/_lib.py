@@ -118,6 +118,35 @@ def hip_runtimes_loaded():
     return seen
 
 
+def _elf_dynamic_strings(path):
+    """(DT_SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read from the file (no loader involved)."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:6] != b"\x7fELF\x02\x01":
+        raise ValueError(f"{path}: not a little-endian ELF64 file")
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    soname, needed = None, []
+    for sec in secs:
+        if sec[1] != 6:                       # SHT_DYNAMIC
+            continue
+        stroff = secs[sec[6]][4]              # sh_link -> the string table's file offset
+        for i in range(sec[5] // 16):
+            tag, val = struct.unpack_from("<qQ", data, sec[4] + 16 * i)
+            if tag == 0:
+                break
+            if tag in (1, 14):                # DT_NEEDED, DT_SONAME
+                end = data.index(b"\0", stroff + val)
+                name = data[stroff + val:end].decode()
+                if tag == 14:
+                    soname = name
+                else:
+                    needed.append(name)
+    return soname, needed
+
+
 def _preload_torch_hip_runtime():
     """ONE HIP runtime per process, whatever the import order.
 
@@ -140,6 +169,16 @@ def _preload_torch_hip_runtime():
         return
     path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
     if os.path.isfile(path):
+        # Only a copy that IS what libmoonrt asks for may stand in for it: the wheel's SONAME must be one of libmoonrt's
+        # DT_NEEDED names.  Otherwise the loader would pull the system runtime in beside it (two runtimes), or libmoonrt would
+        # silently run on a runtime of another major version: leave the system runtime alone then (round-2 advisor finding).
+        try:
+            soname, _ = _elf_dynamic_strings(path)
+            _, needed = _elf_dynamic_strings(LIB_PATH)
+        except (OSError, ValueError, IndexError, __import__("struct").error):
+            return
+        if soname is None or soname not in needed:
+            return
         try:
             C.CDLL(path, mode=C.RTLD_GLOBAL)
             _preloaded_runtime = path

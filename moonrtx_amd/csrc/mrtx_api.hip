@@ -66,6 +66,8 @@ struct mrtx_ctx {
     // kernels + 5 120 persistent waves of the queue do not pay below ~8 M samples (4K: 1 spp 1.34 ms against 1.48, 2 spp 2.28 /
     // 2.41, 4 spp 3.42 / 3.16; cfg1 0.33 / 0.53; tools/spp_sweep.py).  MOONRT_PATH_QUEUE_MIN overrides (0 = always the queue).
     uint64_t path_queue_min = 8000000ull;
+    bool path_fallback_said = false;     // the fall-back to in-wave paths (no memory for the records) was reported
+    bool path_alloc_fail_test = false;   // MOONRT_TEST_PATH_NOMEM=1: test hook, the hand-over allocation "fails"
     int path_refill = 32, path_segmin = 16, path_hitmin = 16, path_waves_env = 0;   // cfg3 sweep: (8,24,16) 16.2 ms, (24,24,16) 14.7, (32,16,16) 14.5, (48,24,16) 21.5
     float* accum = nullptr;
     float* hits = nullptr;
@@ -466,10 +468,11 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
         if ((e = std::getenv("MOONRT_PATH_SEGMIN")) && std::atoi(e) >= -64 && std::atoi(e) <= 64) c->path_segmin = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_HITMIN")) && std::atoi(e) >= -64 && std::atoi(e) <= 64) c->path_hitmin = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_NSUB")) && std::atoi(e) >= 1 && std::atoi(e) <= 16) c->path_nsub = std::atoi(e);
-        if ((e = std::getenv("MOONRT_PATH_GRP")) && std::atoi(e) >= 0 && std::atoi(e) <= 10) c->path_grp_log2 = std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_GRP")) && std::atoi(e) >= 0 && std::atoi(e) <= 5) c->path_grp_log2 = std::atoi(e);   // + njobs_log2 (<= 1) <= 6: 64 chunks per group
         if ((e = std::getenv("MOONRT_PATH_MAX_GB")) && std::atof(e) > 0.0) c->path_budget_bytes = (uint64_t)(std::atof(e) * 1073741824.0);
-        if ((e = std::getenv("MOONRT_PATH_WAVES")) && std::atoi(e) >= 8) c->path_waves_env = std::atoi(e) / 8 * 8;
+        if ((e = std::getenv("MOONRT_PATH_WAVES")) && std::atoi(e) >= 8 * c->path_nsub) c->path_waves_env = std::atoi(e) / 8 * 8;   // every work counter needs a consumer (read after MOONRT_PATH_NSUB)
         if ((e = std::getenv("MOONRT_PATH_QUEUE_MIN")) && std::atof(e) >= 0.0) c->path_queue_min = (uint64_t)std::atof(e);
+        if ((e = std::getenv("MOONRT_TEST_PATH_NOMEM")) && std::atoi(e) == 1) c->path_alloc_fail_test = true;
     }
     c->tiles_x = (cfg->width + c->cfg.tile_w - 1) / c->cfg.tile_w;
     c->tiles_y = (cfg->height + c->cfg.tile_h - 1) / c->cfg.tile_h;
@@ -837,6 +840,78 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         f.n_active = moon_n;
         have_sky = true;
     }
+    // Deferred paths need hand-over buffers and a 24-bit step count per record.  When either is not to be had, the frame is
+    // rendered with the paths inside the render wave instead (mode 1: no buffers, the same frame bit for bit, slower) -- a
+    // render call does not fail where an identical result exists.  Said once per context on stderr.
+    std::vector<FrameC> fs;
+    std::vector<PathQ> pqs;
+    int n_sub = 1;
+    auto fall_back = [&](const char* why) {
+        if (!c->path_fallback_said) {
+            std::fprintf(stderr, "libmoonrt: %s -- this context keeps its paths inside the render wave (same result, slower)\n", why);
+            c->path_fallback_said = true;
+        }
+        mode = 1;
+    };
+    if (mode == 2 && f.kmax >= (1 << 24)) fall_back("marching_step is too small for the 24-bit step count of a hand-over record");
+    if (mode == 2) {
+    // The hand-over buffers are sized for the worst case (64 bytes for each of the 64 lanes of every wave-job of the
+    // launch: 12 GB for the whole-disc cfg3 frame, 129 GB for a cfg4 frame whose every pixel is on the Moon).  A frame
+    // that needs more than path_budget_bytes is rendered in SUB-PARTS of its tile list, one after the other through the
+    // same buffers: render(sub) -> paths(sub) -> resolve(sub); sub-parts cover disjoint pixels.
+    const uint64_t cap_chunks = std::max<uint64_t>(4096, c->path_budget_bytes / (64ull * MRTX_PATH_REC_BYTES));
+    n_sub = 1;
+    {
+        const uint64_t full = mrtx_path_chunks(f, S, nullptr, nullptr);
+        if (full > cap_chunks && f.tile_list != nullptr) n_sub = (int)std::min<uint64_t>((uint64_t)f.n_active, (full + cap_chunks - 1) / cap_chunks);
+    }
+    fs.assign((size_t)n_sub, f);
+    pqs.assign((size_t)n_sub, PathQ());
+    uint64_t chunks = 0;
+    for (int s = 0; s < n_sub; s++) {
+        int a_, b_;
+        part_range(f.n_active, s, n_sub, a_, b_);
+        if (n_sub > 1) { fs[(size_t)s].tile_list = f.tile_list + a_; fs[(size_t)s].n_active = b_ - a_; }
+        std::memset(&pqs[(size_t)s], 0, sizeof(PathQ));
+        chunks = std::max(chunks, mrtx_path_chunks(fs[(size_t)s], S, &pqs[(size_t)s].grid_a, &pqs[(size_t)s].njobs_log2));
+    }
+    if (chunks * 64ull > 0xFFFFFFFFull) {
+        fall_back("the frame holds more wave-jobs than one deferred-path launch can index");
+    } else if (chunks > c->path_cap) {
+        if (c->path_rec) { HIPCHK(c, hipFree(c->path_rec)); c->path_rec = nullptr; }
+        if (c->path_meta) { HIPCHK(c, hipFree(c->path_meta)); c->path_meta = nullptr; }
+        if (c->path_npaths) { HIPCHK(c, hipFree(c->path_npaths)); c->path_npaths = nullptr; }
+        c->path_cap = 0;
+        if (c->path_alloc_fail_test ||
+            hipMalloc((void**)&c->path_rec, (size_t)chunks * 64 * MRTX_PATH_REC_BYTES) != hipSuccess ||
+            hipMalloc((void**)&c->path_meta, (size_t)chunks * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&c->path_npaths, (size_t)chunks + 64) != hipSuccess) {
+            (void)hipGetLastError();                                    // clear the allocation error: the frame is still rendered
+            if (c->path_rec) { (void)hipFree(c->path_rec); c->path_rec = nullptr; }
+            if (c->path_meta) { (void)hipFree(c->path_meta); c->path_meta = nullptr; }
+            if (c->path_npaths) { (void)hipFree(c->path_npaths); c->path_npaths = nullptr; }
+            fall_back("no device memory for the hand-over records");
+        } else {
+            c->path_cap = chunks;
+        }
+    }
+    const size_t n = (size_t)c->path_cap * 64;
+    if (mode == 2 && !c->path_ctr) HIPCHK(c, hipMalloc((void**)&c->path_ctr, 8 * 16 * sizeof(uint32_t)));
+    for (int s = 0; mode == 2 && s < n_sub; s++) {
+        PathQ& pq = pqs[(size_t)s];
+        pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
+        pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n;
+        pq.lane_of = reinterpret_cast<uint32_t*>(pq.c2 + n);
+        pq.npaths = c->path_npaths;
+        pq.meta = c->path_meta;
+        pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
+        pq.n_chunks = (uint32_t)((uint64_t)pq.grid_a << pq.njobs_log2);
+        pq.s_log2 = 0;
+        while ((1 << pq.s_log2) < S) pq.s_log2++;
+        { const int P = 64 / S; const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1; pq.pw_log2 = PW == 8 ? 3 : PW == 4 ? 2 : PW == 2 ? 1 : 0; }
+        pq.refill_min = c->path_refill; pq.seg_min = c->path_segmin; pq.rare_min = c->path_hitmin;
+    }
+    }
     double primary_ms = 0.0, paths_ms = 0.0;
     uint32_t launches = 0;
     if (mode != 2) {
@@ -850,58 +925,6 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         primary_ms = ms;
         launches = ((f.n_active > 0 || !f.tile_list) ? 1u : 0u) + (have_sky ? 1u : 0u);
     } else {
-        // The hand-over buffers are sized for the worst case (64 bytes for each of the 64 lanes of every wave-job of the
-        // launch: 12 GB for the whole-disc cfg3 frame, 129 GB for a cfg4 frame whose every pixel is on the Moon).  A frame
-        // that needs more than path_budget_bytes is rendered in SUB-PARTS of its tile list, one after the other through the
-        // same buffers: render(sub) -> paths(sub) -> resolve(sub); sub-parts cover disjoint pixels.
-        if (f.kmax >= (1 << 24)) return fail(c, MRTX_E_INVALID, "marching_step too small for deferred paths (%d steps per ray; the hand-over record holds 24 bits)", f.kmax);
-        const uint64_t cap_chunks = std::max<uint64_t>(4096, c->path_budget_bytes / (64ull * MRTX_PATH_REC_BYTES));
-        int n_sub = 1;
-        {
-            const uint64_t full = mrtx_path_chunks(f, S, nullptr, nullptr);
-            if (full > cap_chunks && f.tile_list != nullptr) n_sub = (int)std::min<uint64_t>((uint64_t)f.n_active, (full + cap_chunks - 1) / cap_chunks);
-        }
-        std::vector<FrameC> fs((size_t)n_sub, f);
-        std::vector<PathQ> pqs((size_t)n_sub);
-        uint64_t chunks = 0;
-        for (int s = 0; s < n_sub; s++) {
-            int a_, b_;
-            part_range(f.n_active, s, n_sub, a_, b_);
-            if (n_sub > 1) { fs[(size_t)s].tile_list = f.tile_list + a_; fs[(size_t)s].n_active = b_ - a_; }
-            std::memset(&pqs[(size_t)s], 0, sizeof(PathQ));
-            chunks = std::max(chunks, mrtx_path_chunks(fs[(size_t)s], S, &pqs[(size_t)s].grid_a, &pqs[(size_t)s].njobs_log2));
-        }
-        if (chunks * 64ull > 0xFFFFFFFFull) return fail(c, MRTX_E_INVALID, "frame too large for one deferred-path launch (%llu chunks)", (unsigned long long)chunks);
-        if (chunks > c->path_cap) {
-            if (c->path_rec) { HIPCHK(c, hipFree(c->path_rec)); c->path_rec = nullptr; }
-            if (c->path_meta) { HIPCHK(c, hipFree(c->path_meta)); c->path_meta = nullptr; }
-            if (c->path_npaths) { HIPCHK(c, hipFree(c->path_npaths)); c->path_npaths = nullptr; }
-            c->path_cap = 0;
-            if (hipMalloc((void**)&c->path_rec, (size_t)chunks * 64 * MRTX_PATH_REC_BYTES) != hipSuccess ||
-                hipMalloc((void**)&c->path_meta, (size_t)chunks * sizeof(uint32_t)) != hipSuccess ||
-                hipMalloc((void**)&c->path_npaths, (size_t)chunks + 64) != hipSuccess) {
-                (void)hipGetLastError();
-                return fail(c, MRTX_E_NOMEM, "no device memory for %llu path records (%.1f GB); MRTX_F_INWAVE_PATHS needs none",
-                            (unsigned long long)(chunks * 64), (double)chunks * 64 * MRTX_PATH_REC_BYTES / 1e9);
-            }
-            c->path_cap = chunks;
-        }
-        const size_t n = (size_t)c->path_cap * 64;
-        if (!c->path_ctr) HIPCHK(c, hipMalloc((void**)&c->path_ctr, 8 * 16 * sizeof(uint32_t)));
-        for (int s = 0; s < n_sub; s++) {
-            PathQ& pq = pqs[(size_t)s];
-            pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
-            pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n;
-            pq.lane_of = reinterpret_cast<uint32_t*>(pq.c2 + n);
-            pq.npaths = c->path_npaths;
-            pq.meta = c->path_meta;
-            pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
-            pq.n_chunks = (uint32_t)((uint64_t)pq.grid_a << pq.njobs_log2);
-            pq.s_log2 = 0;
-            while ((1 << pq.s_log2) < S) pq.s_log2++;
-            { const int P = 64 / S; const int PW = P >= 32 ? 8 : P >= 8 ? 4 : P >= 2 ? 2 : 1; pq.pw_log2 = PW == 8 ? 3 : PW == 4 ? 2 : PW == 2 ? 1 : 0; }
-            pq.refill_min = c->path_refill; pq.seg_min = c->path_segmin; pq.rare_min = c->path_hitmin;
-        }
         const int wi = (stats ? 2 : 0) + (f.dem_wide ? 1 : 0);
         if (c->path_waves[wi] == 0) {
             int nw = 0;

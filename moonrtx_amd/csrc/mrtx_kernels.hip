@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "mrtx_device.h"
 
@@ -236,10 +237,12 @@ __device__ __forceinline__ void exact_rowcol(const FrameC& f, float pa, float pb
 // [jlo, jhi] (widened by a step each side and by 1e-5 in the bound, which dwarfs every rounding involved,
 // so approximate v_sqrt/v_rcp are fine here).  Steps outside it cannot hit and are not evaluated; the ray's
 // termination test is monotone, so it is enough to apply it at evaluated steps and at the segment end.
-template <bool STATS>
-__device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
-                                          const RayQ& rq, int ka, float rowA, float colA, float q2A, Seg& sg,
-                                          float& rowB, float& colB, float& q2B, uint32_t* cnt) {
+// seg_setup in two phases, so that a caller can put OTHER work between the max-mip fetch and its use (fused_first_segment):
+// seg_anchors = the anchors, the quadratic and WHERE the max-mip is to be read; seg_interval = the skip interval from the cells.
+struct MipTap { uint32_t off; bool usable, two_r, two_c; };
+__device__ __forceinline__ void seg_anchors(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                            int ka, float rowA, float colA, float q2A, Seg& sg,
+                                            float& rowB, float& colB, float& q2B, MipTap& tap) {
     const float sm = (float)(ka + SEG_N / 2) * f.step, sb = (float)(ka + SEG_N) * f.step;
     float rM, cM, q2M;
     exact_rowcol(f, fmaf(sm, da, oa), fmaf(sm, db, ob), fmaf(sm, dc, oc), rM, cM, q2M);
@@ -255,34 +258,50 @@ __device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, f
     sg.c1 = fmaf(-16.0f, sg.c2, (colB - colA) * 0.0625f);
 
     sg.jlo = 1; sg.jhi = SEG_N;
+    tap.usable = false; tap.two_r = tap.two_c = false; tap.off = 0u;
     if (f.mip != nullptr) {
         const int i0 = ((int)floorf(fminf(rowA, fminf(rM, rowB))) - 1) >> f.mip_shift;
         const int i1 = ((int)floorf(fmaxf(rowA, fmaxf(rM, rowB))) + 2) >> f.mip_shift;
         const int j0 = ((int)floorf(fminf(colA, fminf(cM, colB))) - 1) >> f.mip_shift;
         const int j1 = ((int)floorf(fmaxf(colA, fmaxf(cM, colB))) + 2) >> f.mip_shift;
-        const bool usable = !sg.exact & (i1 - i0 <= 1) & (j1 - j0 <= 1) & (i0 >= -1) & (i1 <= f.mip_h) & (j0 >= -1) &
-                            (j1 <= f.mip_w);
-        if (usable) {
-            // the mip is stored in row pairs as well (element (i, j) = (m[i][j], m[i+1][j])): one 16-byte load brings the
-            // 2x2 cells at (i0, j0); the ones the footprint does not reach are ignored, so the bound is the old one
-            const Quad q = *reinterpret_cast<const Quad*>(reinterpret_cast<const char*>(f.mip) +
-                                                          ((uint32_t)((i0 + 1) * f.mip_pitch + j0 + 1) << 3));
-            const bool two_r = i1 > i0, two_c = j1 > j0;
-            const float dmax = fmaxf(fmaxf(q.a, two_r ? q.b : q.a), fmaxf(two_c ? q.c : q.a, (two_r & two_c) ? q.d : q.a));
-            if (STATS) cnt[ST_MIP] += 4;
-            const float rd = f.Rf * dmax;
-            const float T = (rd * rd) * 1.00001f;
-            const float disc = fmaf(rq.b, rq.b, -rq.a * (rq.q0 - T));
-            if (disc < 0.0f) {
-                sg.jlo = SEG_N + 1; sg.jhi = SEG_N;      // the whole segment stays above Dmax
-            } else {
-                const float sq = __builtin_amdgcn_sqrtf(disc), inva = __builtin_amdgcn_rcpf(rq.a);
-                const float u1 = fminf(fmaxf(((-rq.b - sq) * inva - sg.sa) * f.inv_step, -4.0f), 64.0f);
-                const float u2 = fminf(fmaxf(((-rq.b + sq) * inva - sg.sa) * f.inv_step, -4.0f), 64.0f);
-                sg.jlo = min(SEG_N + 1, max(1, (int)floorf(u1) - 1));
-                sg.jhi = min(SEG_N, (int)ceilf(u2) + 1);
-            }
-        }
+        tap.usable = !sg.exact & (i1 - i0 <= 1) & (j1 - j0 <= 1) & (i0 >= -1) & (i1 <= f.mip_h) & (j0 >= -1) &
+                     (j1 <= f.mip_w);
+        tap.two_r = i1 > i0; tap.two_c = j1 > j0;
+        // the mip is stored in row pairs as well (element (i, j) = (m[i][j], m[i+1][j])): one 16-byte load brings the
+        // 2x2 cells at (i0, j0); the ones the footprint does not reach are ignored, so the bound is the old one
+        tap.off = tap.usable ? ((uint32_t)((i0 + 1) * f.mip_pitch + j0 + 1) << 3) : 0u;
+    }
+}
+__device__ __forceinline__ Quad mip_fetch(const FrameC& f, const MipTap& tap) {
+    return *reinterpret_cast<const Quad*>(reinterpret_cast<const char*>(f.mip) + tap.off);
+}
+template <bool STATS>
+__device__ __forceinline__ void seg_interval(const FrameC& f, const RayQ& rq, Seg& sg, const MipTap& tap, const Quad& q,
+                                             uint32_t* cnt) {
+    const float dmax = fmaxf(fmaxf(q.a, tap.two_r ? q.b : q.a), fmaxf(tap.two_c ? q.c : q.a, (tap.two_r & tap.two_c) ? q.d : q.a));
+    if (STATS) cnt[ST_MIP] += 4;
+    const float rd = f.Rf * dmax;
+    const float T = (rd * rd) * 1.00001f;
+    const float disc = fmaf(rq.b, rq.b, -rq.a * (rq.q0 - T));
+    if (disc < 0.0f) {
+        sg.jlo = SEG_N + 1; sg.jhi = SEG_N;      // the whole segment stays above Dmax
+    } else {
+        const float sq = __builtin_amdgcn_sqrtf(disc), inva = __builtin_amdgcn_rcpf(rq.a);
+        const float u1 = fminf(fmaxf(((-rq.b - sq) * inva - sg.sa) * f.inv_step, -4.0f), 64.0f);
+        const float u2 = fminf(fmaxf(((-rq.b + sq) * inva - sg.sa) * f.inv_step, -4.0f), 64.0f);
+        sg.jlo = min(SEG_N + 1, max(1, (int)floorf(u1) - 1));
+        sg.jhi = min(SEG_N, (int)ceilf(u2) + 1);
+    }
+}
+template <bool STATS>
+__device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                          const RayQ& rq, int ka, float rowA, float colA, float q2A, Seg& sg,
+                                          float& rowB, float& colB, float& q2B, uint32_t* cnt) {
+    MipTap tap;
+    seg_anchors(f, oa, ob, oc, da, db, dc, ka, rowA, colA, q2A, sg, rowB, colB, q2B, tap);
+    if (tap.usable) {
+        const Quad q = mip_fetch(f, tap);
+        seg_interval<STATS>(f, rq, sg, tap, q, cnt);
     }
 }
 
@@ -320,11 +339,9 @@ __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float 
 #define MRTX_STEP_BATCH_BOUNCE 1
 #endif
 template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE, int BATCH>
-__device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
-                                          float smax, const Seg& sg, int ka, bool& go, bool& hit, float& sk_out,
-                                          uint32_t* cnt) {
-    int j = sg.jlo;
-    bool more = j <= sg.jhi;
+__device__ __forceinline__ void step_loop_from(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                               float smax, const Seg& sg, int ka, int j, bool more, bool& go, bool& hit,
+                                               float& sk_out, uint32_t* cnt) {
     if (EXACTABLE || BATCH == 1) {
         while (more) {
             const int k = ka + j;
@@ -381,6 +398,14 @@ __device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, f
     }
 }
 
+template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE, int BATCH>
+__device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
+                                          float smax, const Seg& sg, int ka, bool& go, bool& hit, float& sk_out,
+                                          uint32_t* cnt) {
+    step_loop_from<WIDE, PRIMARY, STATS, EXACTABLE, BATCH>(f, oa, ob, oc, da, db, dc, smax, sg, ka, sg.jlo, sg.jlo <= sg.jhi,
+                                                           go, hit, sk_out, cnt);
+}
+
 // STATS builds only: the spec counts a DEM evaluation at every step that is still inside; add the skipped ones.
 template <bool PRIMARY>
 __device__ __forceinline__ uint32_t count_in_steps(const FrameC& f, float oa, float ob, float oc, float da, float db,
@@ -419,7 +444,15 @@ struct MarchState {
 // both (+4 texels for taps and the quadratic's bulge) inside Cc, otherwise nothing is cut.  Then the last step that can
 // matter is where r^2(s) reaches (R Dc)^2 (1 + 1e-5).  Approximate v_sqrt / v_rcp are fine: every bound is padded.
 // Radiance, hits and the spec counters are unchanged (MRTX_F_NO_SKIP switches this off together with the max-mip).
-__device__ __forceinline__ int horizon_kend(const FrameC& f, const MarchState& m) {
+// the horizon-mip cell of a march origin at texel (rowA, colA): one look-up serves every ray that starts there
+__device__ __forceinline__ float horizon_cell(const FrameC& f, float rowA, float colA) {
+    int i = (int)floorf(rowA) >> CF(f)->hm_shift, j = (int)floorf(colA) >> CF(f)->hm_shift;
+    i = max(0, min(i, CF(f)->hm_h - 1)); j = max(0, min(j, CF(f)->hm_w - 1));
+    return CF(f)->hmip[i * CF(f)->hm_w + j];
+}
+// PRE: the caller has fetched horizon_cell(f, m.rowA, m.colA) already (`cell_pre`): same bound, no load here
+template <bool PRE = false>
+__device__ __forceinline__ int horizon_kend(const FrameC& f, const MarchState& m, float cell_pre = 0.0f) {
     int kend = f.kmax;
     const float* hm = CF(f)->hmip;
     if (hm != nullptr && m.rq.b >= 0.0f) {
@@ -433,9 +466,7 @@ __device__ __forceinline__ int horizon_kend(const FrameC& f, const MarchState& m
         const float dcol = fmaf(phi * CF(f)->hm_kcol, inv_cos * __builtin_amdgcn_rcpf(fmaxf(den, 0.25f)), 4.0f);
         const float cell = CF(f)->hm_cell;
         if ((c >= 0.0f) & (phi <= 0.25f) & (den >= 0.5f) & (drow <= cell) & (dcol <= cell)) {
-            int i = (int)floorf(m.rowA) >> CF(f)->hm_shift, j = (int)floorf(m.colA) >> CF(f)->hm_shift;
-            i = max(0, min(i, CF(f)->hm_h - 1)); j = max(0, min(j, CF(f)->hm_w - 1));
-            const float rd = f.Rf * hm[i * CF(f)->hm_w + j];
+            const float rd = f.Rf * (PRE ? cell_pre : horizon_cell(f, m.rowA, m.colA));
             const float d = (rd * rd) * 1.00001f - q0;
             if (d <= 0.0f) kend = 0;
             else {
@@ -463,9 +494,9 @@ __device__ __forceinline__ uint32_t steps_after(const FrameC& f, const MarchStat
 // ... with the exact texel coordinates of the origin already known (m.rowA, m.colA)
 // LAZY_KEND (path_kernel): the horizon bound is left open (m.kend = -1) and looked up by the first segment set-up, in the
 // same memory round as that segment's max-mip fetch, instead of costing a round of its own here.
-template <bool PRIMARY, bool STATS, bool LAZY_KEND = false>
+template <bool PRIMARY, bool STATS, bool LAZY_KEND = false, bool PRE_CELL = false>
 __device__ __forceinline__ bool march_begin_at(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
-                                               MarchState& m, uint32_t* cnt) {
+                                               MarchState& m, uint32_t* cnt, float cell_pre = 0.0f) {
     m.oa = oa; m.ob = ob; m.oc = oc; m.da = da; m.db = db; m.dc = dc;
     m.q2A = fmaf(ob, ob, oa * oa);
     m.rq.q0 = fmaf(oc, oc, m.q2A);
@@ -483,7 +514,7 @@ __device__ __forceinline__ bool march_begin_at(const FrameC& f, float oa, float 
         if (LAZY_KEND) {
             m.kend = -1;
         } else {
-            m.kend = horizon_kend(f, m);
+            m.kend = horizon_kend<PRE_CELL>(f, m, cell_pre);
             if (go && m.kend < 1) {          // already above everything in reach: no step can hit
                 if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, 1);
                 go = false;
@@ -500,6 +531,28 @@ __device__ __forceinline__ bool march_begin(const FrameC& f, float oa, float ob,
     float q2;
     exact_rowcol(f, oa, ob, oc, m.rowA, m.colA, q2);
     return march_begin_at<PRIMARY, STATS, LAZY_KEND>(f, oa, ob, oc, da, db, dc, m, cnt);
+}
+
+// End of a segment whose steps are through: a ray that is still marching (`go`) may have ended inside the skipped tail, or
+// is cut by its horizon bound; the march state moves on to the next segment.
+template <bool PRIMARY, bool STATS>
+__device__ __forceinline__ void segment_tail(const FrameC& f, MarchState& m, float smax, const Seg& sg, bool& go, float rowB,
+                                             float colB, float q2B, uint32_t* cnt) {
+    const float oa = m.oa, ob = m.ob, oc = m.oc, da = m.da, db = m.db, dc = m.dc;
+    const int ka = m.ka;
+    if (go) {
+        // still marching after the last evaluated step: did the ray end inside the skipped tail?
+        if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, max(sg.jhi + 1, 1), SEG_N);
+        const int k = ka + SEG_N;
+        const float sk = (float)k * f.step;
+        const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
+        go = (PRIMARY ? (sk <= smax) : (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f)) & (k < f.kmax);
+        if (!PRIMARY && go && k >= m.kend) {           // cut by the horizon bound: the rest of the ray is above the terrain
+            if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, k + 1);
+            go = false;
+        }
+    }
+    m.ka = ka + SEG_N; m.rowA = rowB; m.colA = colB; m.q2A = q2B;
 }
 
 // ONE 16-step segment of a march (the lanes that call it are still marching): anchors + skip interval, the steps
@@ -530,19 +583,7 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
     cnt[15] += PRIMARY ? 1u : 0u;
 #endif
 #endif
-    if (go) {
-        // still marching after the last evaluated step: did the ray end inside the skipped tail?
-        if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, max(sg.jhi + 1, 1), SEG_N);
-        const int k = ka + SEG_N;
-        const float sk = (float)k * f.step;
-        const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
-        go = (PRIMARY ? (sk <= smax) : (fmaf(pc, pc, fmaf(pb, pb, pa * pa)) <= f.R2f)) & (k < f.kmax);
-        if (!PRIMARY && go && k >= m.kend) {           // cut by the horizon bound: the rest of the ray is above the terrain
-            if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, k + 1);
-            go = false;
-        }
-    }
-    m.ka = ka + SEG_N; m.rowA = rowB; m.colA = colB; m.q2A = q2B;
+    segment_tail<PRIMARY, STATS>(f, m, smax, sg, go, rowB, colB, q2B, cnt);
 }
 
 // Coarse march s_k = k*step, k = 1, 2, ...; returns true and s_k at the first sample at/below the surface.
@@ -840,6 +881,108 @@ __device__ __forceinline__ float nearest_capsule(const FrameC& f, int lt, float 
     return which >= 0 ? best : -1.0e30f;
 }
 
+// ---- render_kernel<MODE 2>, an experiment that is NOT the shipped order (round 3; kept as an A/B switch with its measurement):
+// the shadow ray of the first vertex and the FIRST segment of its continuation ray marched TOGETHER.  Both rays leave the same
+// point (vertex + scene_epsilon * normal: light_sample and continue_path build it with the same expression), so its exact texel
+// coordinates and its horizon-mip cell are evaluated / fetched once; the two segment set-ups are issued back to back (both
+// max-mip fetches in flight together) and the step loop evaluates the next steps of BOTH rays per iteration, so that the trial
+// segment rides the memory rounds of the shadow march instead of adding ~4 dependent rounds of its own after it.  Per ray the
+// evaluations, their order and every counter are those of march_begin_at + march_segment: bit-identical (tools/quick_parity.py).
+// Measured at cfg3, S1, (2,4) (gpurun_out/r3b, profiles/r03_mode2_ab.md): render_kernel<MODE 2> 18.9 ms as shipped;
+//   MRTX_FUSED_TRIAL=1: 22.7 ms (147 VGPRs: 3 waves per SIMD instead of 4), 23.6 ms when held to 128 VGPRs (16 spilled);
+//   MRTX_FUSED_TRIAL=2 (only the origin's coordinates and horizon cell shared, marches in sequence): 19.0 ms -- 65 VALU per
+//   sample less buy nothing;
+// and the shipped kernel under an occupancy cap (tools/occ_sweep.sh): 3 waves per SIMD 23.4 ms, 4 (as shipped) 18.9 ms, while a
+// launch bound of 5 / 6 waves (96 / 80 VGPRs, 22+ spilled) gives 22.2 / 23.3 ms.  The kernel is bound by the dependent-load
+// rounds a wave goes through times the waves a SIMD can hold; two more live march states cost a wave slot, which is worth
+// more than the four rounds the fusion hides.
+#ifndef MRTX_FUSED_TRIAL
+#define MRTX_FUSED_TRIAL 0     // 1 = fused first segment, 2 = shared origin only, 0 = one march after the other (ships)
+#endif
+#if MRTX_FUSED_TRIAL == 1
+template <bool WIDE, bool STATS>
+__device__ __forceinline__ void fused_first_segment(const FrameC& f, MarchState& ms, MarchState& mt, Seg& sgs, Seg& sgt,
+                                                    bool& go_s, bool& go_t, bool& hit_s, bool& hit_t, float& sk_s, float& sk_t,
+                                                    uint32_t* cnt) {
+    constexpr int B = 2;
+    float rBs, cBs, qBs, rBt, cBt, qBt;
+    MipTap tap_s, tap_t;
+    seg_anchors(f, ms.oa, ms.ob, ms.oc, ms.da, ms.db, ms.dc, ms.ka, ms.rowA, ms.colA, ms.q2A, sgs, rBs, cBs, qBs, tap_s);
+    seg_anchors(f, mt.oa, mt.ob, mt.oc, mt.da, mt.db, mt.dc, mt.ka, mt.rowA, mt.colA, mt.q2A, sgt, rBt, cBt, qBt, tap_t);
+    tap_s.usable &= go_s; tap_t.usable &= go_t;
+    if (f.mip != nullptr) {                                  // wave-uniform
+        tap_s.off = tap_s.usable ? tap_s.off : 0u; tap_t.off = tap_t.usable ? tap_t.off : 0u;
+        const Quad qs = mip_fetch(f, tap_s), qt = mip_fetch(f, tap_t);     // unconditional: both in flight together
+        if (tap_s.usable) seg_interval<STATS>(f, ms.rq, sgs, tap_s, qs, cnt);
+        if (tap_t.usable) seg_interval<STATS>(f, mt.rq, sgt, tap_t, qt, cnt);
+    }
+    sgs.jhi = max(min(sgs.jhi, ms.kend - ms.ka), sgs.jlo - 1);   // steps beyond kend cannot be at/below the surface
+    sgt.jhi = max(min(sgt.jhi, mt.kend - mt.ka), sgt.jlo - 1);
+    if (STATS) {
+        if (go_s) cnt[ST_HEIGHT] += count_in_steps<false>(f, ms.oa, ms.ob, ms.oc, ms.da, ms.db, ms.dc, 0.0f, ms.ka, 1, sgs.jlo - 1);
+        if (go_t) cnt[ST_HEIGHT] += count_in_steps<false>(f, mt.oa, mt.ob, mt.oc, mt.da, mt.db, mt.dc, 0.0f, mt.ka, 1, sgt.jlo - 1);
+    }
+    int js = sgs.jlo, jt = sgt.jlo;
+    bool more_s = go_s & (js <= sgs.jhi), more_t = go_t & (jt <= sgt.jhi);
+    if (__ballot((go_s & sgs.exact) | (go_t & sgt.exact)) == 0ull) {
+        // both rays step while both have lanes stepping; what is left of either one afterwards runs in its own loop below
+        while (__ballot(more_s) != 0ull && __ballot(more_t) != 0ull) {
+            float surf_s[B], surf_t[B];
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                // steps past jhi are evaluated at the segment's last step instead (inside the quadratic's range), as in step_loop
+                const float us = ((float)(ms.ka + min(js + i, SEG_N)) * f.step - sgs.sa) * f.inv_step;
+                surf_s[i] = f.Rf * dem_march<WIDE>(f, fmaf(us, fmaf(us, sgs.r2, sgs.r1), sgs.ra), fmaf(us, fmaf(us, sgs.c2, sgs.c1), sgs.ca));
+                const float ut = ((float)(mt.ka + min(jt + i, SEG_N)) * f.step - sgt.sa) * f.inv_step;
+                surf_t[i] = f.Rf * dem_march<WIDE>(f, fmaf(ut, fmaf(ut, sgt.r2, sgt.r1), sgt.ra), fmaf(ut, fmaf(ut, sgt.c2, sgt.c1), sgt.ca));
+            }
+            bool act = more_s;
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const int k = ms.ka + js + i;
+                const float sk = (float)k * f.step;
+                const float pa = fmaf(sk, ms.da, ms.oa), pb = fmaf(sk, ms.db, ms.ob), pc = fmaf(sk, ms.dc, ms.oc);
+                const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+                const bool in = (r2 <= f.R2f) & (k <= f.kmax);
+                const bool bel = r2 <= surf_s[i] * surf_s[i];
+                if (STATS) { cnt[ST_HEIGHT] += (act & in) ? 1u : 0u; cnt[ST_FETCH] += act ? 1u : 0u; }
+                hit_s = act ? (in & bel) : hit_s;
+                go_s = act ? (in & !bel) : go_s;
+                sk_s = act ? sk : sk_s;
+                act = act & go_s & (js + i + 1 <= sgs.jhi);
+            }
+            js += B; more_s = act;
+            act = more_t;
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const int k = mt.ka + jt + i;
+                const float sk = (float)k * f.step;
+                const float pa = fmaf(sk, mt.da, mt.oa), pb = fmaf(sk, mt.db, mt.ob), pc = fmaf(sk, mt.dc, mt.oc);
+                const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+                const bool in = (r2 <= f.R2f) & (k <= f.kmax);
+                const bool bel = r2 <= surf_t[i] * surf_t[i];
+                if (STATS) { cnt[ST_HEIGHT] += (act & in) ? 1u : 0u; cnt[ST_FETCH] += act ? 1u : 0u; }
+                hit_t = act ? (in & bel) : hit_t;
+                go_t = act ? (in & !bel) : go_t;
+                sk_t = act ? sk : sk_t;
+                act = act & go_t & (jt + i + 1 <= sgt.jhi);
+            }
+            jt += B; more_t = act;
+        }
+        if (__ballot(more_s) != 0ull)
+            step_loop_from<WIDE, false, STATS, false, MRTX_STEP_BATCH>(f, ms.oa, ms.ob, ms.oc, ms.da, ms.db, ms.dc, 0.0f, sgs, ms.ka, js, more_s, go_s, hit_s, sk_s, cnt);
+        if (__ballot(more_t) != 0ull)
+            step_loop_from<WIDE, false, STATS, false, MRTX_TRIAL_BATCH>(f, mt.oa, mt.ob, mt.oc, mt.da, mt.db, mt.dc, 0.0f, sgt, mt.ka, jt, more_t, go_t, hit_t, sk_t, cnt);
+    } else {                                                 // a lane needs exact texel coordinates at every step (seam / pole)
+        step_loop_from<WIDE, false, STATS, true, 1>(f, ms.oa, ms.ob, ms.oc, ms.da, ms.db, ms.dc, 0.0f, sgs, ms.ka, js, more_s, go_s, hit_s, sk_s, cnt);
+        step_loop_from<WIDE, false, STATS, true, 1>(f, mt.oa, mt.ob, mt.oc, mt.da, mt.db, mt.dc, 0.0f, sgt, mt.ka, jt, more_t, go_t, hit_t, sk_t, cnt);
+    }
+    segment_tail<false, STATS>(f, ms, 0.0f, sgs, go_s, rBs, cBs, qBs, cnt);
+    segment_tail<false, STATS>(f, mt, 0.0f, sgt, go_t, rBt, cBt, qBt, cnt);
+}
+
+#endif   // MRTX_FUSED_TRIAL == 1
+
 struct SampleOut {
     float c0, c1, c2, hitflag;
     float h0, h1, h2, h3;
@@ -856,6 +999,9 @@ struct SampleOut {
 template <bool STATS, bool WIDE, int MODE, bool OVERLAY>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int y, uint32_t gs, SampleOut& o,
                                              uint32_t* cnt) {
+    // (writing the hit record from here, as soon as it is known, instead of carrying it to the end of the wave was measured:
+    // 13.33 ms against 13.21 for the direct frame, no difference with paths -- the single late store stays)
+    auto emit_hit = [&](float h0, float h1, float h2, float h3) { o.h0 = h0; o.h1 = h1; o.h2 = h2; o.h3 = h3; };
     constexpr bool BOUNCE = MODE == 1, DEFER = MODE == 2;
     constexpr int BATCH = BOUNCE ? MRTX_STEP_BATCH_BOUNCE : MRTX_STEP_BATCH;   // incoherent bounce rays waste the speculative fetches
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
@@ -879,6 +1025,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     dx = dx * inv_len; dy = dy * inv_len; dz = dz * inv_len;
     if (MODE == 3) {
         if (CF(f)->bg) env_lookup<STATS>(f, dx, dy, dz, o.c0, o.c1, o.c2, cnt);  // D7
+        emit_hit(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
 
@@ -962,10 +1109,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         const CFloat c = (CFloat)CF(f)->caps + 12 * cap;
         o.c0 = c[8]; o.c1 = c[9]; o.c2 = c[10];
         o.hitflag = 1.0f;
-        o.h0 = CF(f)->centerf[0] + fmaf(cap_s, dx, cr0);
-        o.h1 = CF(f)->centerf[1] + fmaf(cap_s, dy, cr1);
-        o.h2 = CF(f)->centerf[2] + fmaf(cap_s, dz, cr2);
-        o.h3 = (float)tc0 + cap_s;
+        emit_hit(CF(f)->centerf[0] + fmaf(cap_s, dx, cr0), CF(f)->centerf[1] + fmaf(cap_s, dy, cr1),
+                 CF(f)->centerf[2] + fmaf(cap_s, dz, cr2), (float)tc0 + cap_s);
         return;
     }
     if (!hit) {
@@ -976,14 +1121,12 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 const float t = bq - sqrtf(dq);
                 o.c0 = o.c1 = o.c2 = CF(f)->sun_rad;
                 o.hitflag = 1.0f;
-                o.h0 = fmaf(t, dx, CF(f)->eyef[0]);
-                o.h1 = fmaf(t, dy, CF(f)->eyef[1]);
-                o.h2 = fmaf(t, dz, CF(f)->eyef[2]);
-                o.h3 = t;
+                emit_hit(fmaf(t, dx, CF(f)->eyef[0]), fmaf(t, dy, CF(f)->eyef[1]), fmaf(t, dz, CF(f)->eyef[2]), t);
                 return;
             }
         }
         if (CF(f)->bg) env_lookup<STATS>(f, dx, dy, dz, o.c0, o.c1, o.c2, cnt);  // D7
+        emit_hit(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
 
@@ -994,14 +1137,75 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     hit_vertex<STATS, WIDE>(f, fmaf(lo, da, pa), fmaf(lo, db, pb), fmaf(lo, dc, pc), v, cnt);
     PROF_END(4);
     o.hitflag = 1.0f;
-    o.h0 = CF(f)->centerf[0] + fmaf(v.pc, CF(f)->Mf[2][0], fmaf(v.pb, CF(f)->Mf[1][0], v.pa * CF(f)->Mf[0][0]));
-    o.h1 = CF(f)->centerf[1] + fmaf(v.pc, CF(f)->Mf[2][1], fmaf(v.pb, CF(f)->Mf[1][1], v.pa * CF(f)->Mf[0][1]));
-    o.h2 = CF(f)->centerf[2] + fmaf(v.pc, CF(f)->Mf[2][2], fmaf(v.pb, CF(f)->Mf[1][2], v.pa * CF(f)->Mf[0][2]));
-    o.h3 = (float)t0 + lo;
+    emit_hit(CF(f)->centerf[0] + fmaf(v.pc, CF(f)->Mf[2][0], fmaf(v.pb, CF(f)->Mf[1][0], v.pa * CF(f)->Mf[0][0])),
+             CF(f)->centerf[1] + fmaf(v.pc, CF(f)->Mf[2][1], fmaf(v.pb, CF(f)->Mf[1][1], v.pa * CF(f)->Mf[0][1])),
+             CF(f)->centerf[2] + fmaf(v.pc, CF(f)->Mf[2][2], fmaf(v.pb, CF(f)->Mf[1][2], v.pa * CF(f)->Mf[0][2])),
+             (float)t0 + lo);
 
     float t0r = 1.0f, t1r = 1.0f, t2r = 1.0f;   // path throughput
     uint32_t seg = 1;
     float ul1 = u2, ul2 = u3;
+#if MRTX_FUSED_TRIAL && MRTX_TRIAL_SEGMENT && !defined(MRTX_PROF)
+    if (DEFER) {
+        // Vertex 1: its light sample's shadow ray and the first segment of its continuation ray share their origin and are
+        // marched together (fused_first_segment); then the rest of the shadow march.  Same evaluations, results and counters
+        // as direct_light() followed by the trial segment below (MRTX_FUSED_TRIAL = 0).
+        float so_a, so_b, so_c, sw_a, sw_b, sw_c, carried = 0.0f;
+        const bool have_s = light_sample(f, v, ul1, ul2, so_a, so_b, so_c, sw_a, sw_b, sw_c, carried);
+        if (STATS && have_s) cnt[ST_SHADOW]++;
+        const float k0 = t0r * v.al0, k1 = t1r * v.al1, k2 = t2r * v.al2;      // the direct term's weights: throughput BEFORE the bounce
+        const bool have_c = continue_path(f, v, ks, 1u, t0r, t1r, t2r, o.oa, o.ob, o.oc, o.da, o.db, o.dc);
+        if (STATS && have_c) cnt[ST_BOUNCE]++;
+        float row0, col0, q2o;
+        exact_rowcol(f, so_a, so_b, so_c, row0, col0, q2o);                     // ONE evaluation for both rays' origin
+        const bool hm_on = CF(f)->hmip != nullptr;                              // wave-uniform
+        const float cell = hm_on ? horizon_cell(f, row0, col0) : 0.0f;         // ... and one horizon-mip look-up
+        MarchState ms, mt;
+        ms.rowA = mt.rowA = row0; ms.colA = mt.colA = col0;
+        // an absent ray is a ray of length zero from the same origin: its set-up arithmetic stays finite and is discarded
+        // (b = 0 and a = 0 make horizon_kend's chord bound infinite, so it never cuts and never counts anything)
+        bool go_s = march_begin_at<false, STATS, false, true>(f, so_a, so_b, so_c, have_s ? sw_a : 0.0f, have_s ? sw_b : 0.0f,
+                                                              have_s ? sw_c : 0.0f, ms, cnt, cell) & have_s;
+        bool go_t = march_begin_at<false, STATS, false, true>(f, so_a, so_b, so_c, have_c ? o.da : 0.0f, have_c ? o.db : 0.0f,
+                                                              have_c ? o.dc : 0.0f, mt, cnt, cell) & have_c;
+        bool hit_s = false, hit_t = false;
+        float sk_s = 0.0f, sk_t = 0.0f;
+        Seg sgs, sgt;
+#if MRTX_FUSED_TRIAL == 2     // A/B: shared origin coordinates and horizon cell only, the two marches one after the other
+        while (go_s) march_segment<WIDE, false, STATS, BATCH>(f, ms, 0.0f, sgs, go_s, hit_s, sk_s, cnt);
+        if (go_t) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH>(f, mt, 0.0f, sgt, go_t, hit_t, sk_t, cnt);
+#else
+        const bool any_s = __ballot(go_s) != 0ull, any_t = __ballot(go_t) != 0ull;
+        if (any_s && any_t) {
+            fused_first_segment<WIDE, STATS>(f, ms, mt, sgs, sgt, go_s, go_t, hit_s, hit_t, sk_s, sk_t, cnt);
+        } else if (any_t) {
+            if (go_t) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH>(f, mt, 0.0f, sgt, go_t, hit_t, sk_t, cnt);
+        }
+        while (go_s) march_segment<WIDE, false, STATS, BATCH>(f, ms, 0.0f, sgs, go_s, hit_s, sk_s, cnt);
+#endif
+        const float wgt = (have_s && !hit_s) ? carried : 0.0f;
+        o.c0 = fmaf(k0, wgt, o.c0);
+        o.c1 = fmaf(k1, wgt, o.c1);
+        o.c2 = fmaf(k2, wgt, o.c2);
+        if (have_c) {
+            o.row = row0; o.col = col0;
+            o.t0 = t0r; o.t1 = t1r; o.t2 = t2r;
+            o.ks = ks; o.aux = 0u;
+            if (!go_t && !hit_t) {
+                escaped_path<STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, t0r, t1r, t2r, o.c0, o.c1, o.c2, cnt);
+            } else {
+                o.path = true;
+                if (hit_t) {
+                    o.aux = MRTX_REC_HIT | ((uint32_t)(int)rintf(sk_t * f.inv_step) << 8);
+                } else {
+                    o.aux = MRTX_REC_RESUME | ((uint32_t)mt.kend << 8);
+                    o.row = mt.rowA; o.col = mt.colA;
+                }
+            }
+        }
+        return;
+    }
+#endif
     for (;;) {
         PROF_BEGIN(5);
         const float wgt = direct_light<STATS, WIDE, BATCH>(f, v, ul1, ul2, cnt);
@@ -1030,7 +1234,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
 #pragma unroll
                 for (int i = 0; i < 16; i++) tcnt[i] = 0;
 #else
-                uint32_t tcnt[ST_N];
+                uint32_t tcnt_store[STATS ? ST_N : 1];
+                uint32_t* const tcnt = STATS ? tcnt_store : nullptr;
 #endif
                 if (STATS) {
 #pragma unroll
@@ -1179,7 +1384,10 @@ render_kernel(const FrameC f, const PathQ pq) {
         for (int i = 0; i < 16; i++) cnt[i] = 0;
     }
 #else
-    uint32_t cnt[ST_N];
+    // the production kernels carry no counters: a null pointer instead of a dead array (which still cost every wave a
+    // private segment: 36 bytes of scratch that no instruction touched)
+    uint32_t cnt_store[STATS ? ST_N : 1];
+    uint32_t* const cnt = STATS ? cnt_store : nullptr;
 #endif
     if (STATS) {
 #pragma unroll
@@ -1194,12 +1402,7 @@ render_kernel(const FrameC f, const PathQ pq) {
         const int x = px0 + jx * PW + (p % PW), y = py0 + jy * PH + (p / PW);
         if (px0 + jx * PW >= f.W || py0 + jy * PH >= f.H) continue;  // wave-uniform
         const bool inb = x < f.W && y < f.H;
-        const int64_t pix = (int64_t)y * f.W + x;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if (f.first_block != 0 && inb) {
-            const float4 prev = reinterpret_cast<const float4*>(CF(f)->accum)[pix];
-            s0 = prev.x; s1 = prev.y; s2 = prev.z; s3 = prev.w;
-        }
         SampleOut o;
         o.h0 = o.h1 = o.h2 = o.h3 = 0.f;
         o.path = false;
@@ -1210,6 +1413,12 @@ render_kernel(const FrameC f, const PathQ pq) {
             PROF_BEGIN(0);
             if (inb) trace_sample<STATS, WIDE, MODE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
             PROF_END(0);
+            if (blk == 0 && f.first_block != 0 && inb && s == 0) {
+                // the running sums of earlier launches are fetched HERE, not before the first block was traced (four registers
+                // less while it is); the order of the additions is the spec's: ((prev + b0) + b1) + ...
+                const float4 prev = reinterpret_cast<const float4*>(CF(f)->accum)[(int64_t)y * f.W + x];
+                s0 = prev.x; s1 = prev.y; s2 = prev.z; s3 = prev.w;
+            }
             if (DEFER) deferred = __ballot(o.path) != 0ull;
             if (DEFER && deferred) {
                 // Some path of this wave continues: every lane hands its sample to path_kernel / resolve_paths_kernel
@@ -1240,10 +1449,8 @@ render_kernel(const FrameC f, const PathQ pq) {
             }
             s3 += tree_sum<S>(o.hitflag);
         }
-        if (inb && s == 0) {
-            reinterpret_cast<float4*>(CF(f)->accum)[pix] = make_float4(s0, s1, s2, s3);
-            reinterpret_cast<float4*>(CF(f)->hits)[pix] = make_float4(o.h0, o.h1, o.h2, o.h3);
-        }
+        if (inb && s == 0) reinterpret_cast<float4*>(CF(f)->accum)[(int64_t)y * f.W + x] = make_float4(s0, s1, s2, s3);
+        if (inb && s == 0) reinterpret_cast<float4*>(CF(f)->hits)[(int64_t)y * f.W + x] = make_float4(o.h0, o.h1, o.h2, o.h3);
     }
 
 #ifdef MRTX_PROF
@@ -1324,7 +1531,8 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     uint32_t next_g = 0;
     if (lane == 0 && more) next_g = atomicAdd(ctr, 1u);
     uint32_t iterations = 0;
-    uint32_t cnt[ST_N];
+    uint32_t cnt_store[STATS ? ST_N : 1];
+    uint32_t* const cnt = STATS ? cnt_store : nullptr;
     if (STATS) {
 #pragma unroll
         for (int i = 0; i < ST_N; i++) cnt[i] = 0;
@@ -2124,7 +2332,9 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, int mode, bool
         q = *pq;
     }
     const bool wide = f.dem_wide != 0;
-#define MRTX_LAUNCH(SV, ST, WD, MD, OV) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, MD, OV>), grid, block, 0, st, fr, q)
+    // measurement aid: MOONRT_DEV_LDS=<bytes> of dynamic LDS per workgroup caps the waves a CU holds (13312 -> 12 = 3 per SIMD)
+    static const unsigned dev_lds = getenv("MOONRT_DEV_LDS") ? (unsigned)atoi(getenv("MOONRT_DEV_LDS")) : 0u;
+#define MRTX_LAUNCH(SV, ST, WD, MD, OV) hipLaunchKernelGGL((mrtx::render_kernel<SV, ST, WD, MD, OV>), grid, block, dev_lds, st, fr, q)
 #define MRTX_CASE3(SV, MD, OV)                                                                                     \
         if (wide) { if (stats) MRTX_LAUNCH(SV, true, true, MD, OV); else MRTX_LAUNCH(SV, false, true, MD, OV); }   \
         else { if (stats) MRTX_LAUNCH(SV, true, false, MD, OV); else MRTX_LAUNCH(SV, false, false, MD, OV); }
@@ -2136,7 +2346,10 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, int mode, bool
         else { MRTX_CASE2(SV, 0) }   \
         break;
     switch (S) {
-        MRTX_CASE(1) MRTX_CASE(2) MRTX_CASE(4) MRTX_CASE(8) MRTX_CASE(16) MRTX_CASE(32) MRTX_CASE(64)
+#ifndef MRTX_DEV_ONLY_S64      // tools/build_variant.sh ... -DMRTX_DEV_ONLY_S64: A/B builds for bench.py compile in a fifth of the time
+        MRTX_CASE(1) MRTX_CASE(2) MRTX_CASE(4) MRTX_CASE(8) MRTX_CASE(16) MRTX_CASE(32)
+#endif
+        MRTX_CASE(64)
         default: return hipErrorInvalidValue;
     }
 #undef MRTX_CASE
@@ -2166,7 +2379,11 @@ int mrtx_path_waves(bool stats, bool wide, int* out) {
 }
 hipError_t mrtx_launch_paths(const FrameC& f, const PathQ& pq, int S, bool stats, int n_waves, hipStream_t st) {
     if (pq.n_chunks == 0) return hipSuccess;
-    if (n_waves < 8 || (n_waves & 7) || !pq.counters || pq.n_sub < 1) return hipErrorInvalidValue;
+    // every (label, sub) counter needs a consumer: blocks b with (b >> 3) % n_sub == sub exist only if n_waves >= 8 * n_sub;
+    // a group's chunk counts live in the lanes of one wave: at most 64 chunks per group
+    if (n_waves < 8 * pq.n_sub || (n_waves & 7) || !pq.counters || pq.n_sub < 1 || pq.n_sub > 16 || pq.grp_log2 < 0 ||
+        pq.grp_log2 + pq.njobs_log2 > 6)
+        return hipErrorInvalidValue;
     const bool wide = f.dem_wide != 0;
     const dim3 grid((unsigned)n_waves), block(64);
     if (stats) { if (wide) hipLaunchKernelGGL((mrtx::path_kernel<true, true>), grid, block, 0, st, f, pq);

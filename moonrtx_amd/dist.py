@@ -106,11 +106,15 @@ class FrameGather:
             st = r.render(n_blocks)
             self.gather()
             return st
+        import time
         import torch.distributed as dist
         works, total = [], None
+        t_pack = t_wait = t_unpack = 0.0
         for k in range(P):
             st = r.render_part(n_blocks, k, P)                      # returns when the piece is rendered
+            t0 = time.perf_counter()
             off, ln = r.pack_part(self.send.data_ptr(), k, P)       # synchronous on the renderer's stream
+            t_pack += time.perf_counter() - t0
             a, b = off // 4, (off + ln) // 4
             if b > a:                                               # same cut on every rank
                 works.append(dist.gather(self.send[a:b], [t[a:b] for t in self.recv] if self.rank == 0 else None,
@@ -120,12 +124,17 @@ class FrameGather:
             else:
                 for key, v in st.items():
                     total[key] += v
+        t0 = time.perf_counter()
         for w in works:
             w.wait()
         self.torch.cuda.synchronize()
+        t_wait = time.perf_counter() - t0                           # what of the exchange the rendering did not hide
         self.last_bytes = r.shard_bytes_active()
         if self.rank == 0:
+            t0 = time.perf_counter()
             r.unpack_all([t.data_ptr() for t in self.recv])
+            t_unpack = time.perf_counter() - t0
+        self.last_timing = {"parts": P, "pack_ms": t_pack * 1e3, "gather_wait_ms": t_wait * 1e3, "unpack_ms": t_unpack * 1e3}
         return total
 
     def gather(self):
@@ -139,6 +148,8 @@ class FrameGather:
             n = self.r.shard_bytes_active() // 4          # same on every rank: a function of the (identical) scene
         self.last_bytes = n * 4
         self.r.pack_shard(self.send.data_ptr())          # synchronous on the renderer's stream
+        import time
+        t0 = time.perf_counter()
         if n == 0:
             pass
         elif self.host_staged:
@@ -151,9 +162,11 @@ class FrameGather:
             dist.gather(self.send[:n], [t[:n] for t in self.recv] if self.rank == 0 else None, dst=0)
         if self.send.is_cuda:
             torch.cuda.synchronize()
+        t1 = time.perf_counter()
         if self.rank == 0:
             if hasattr(self.r, "unpack_all"):
                 self.r.unpack_all([t.data_ptr() for t in self.recv])
             else:
                 for src in range(1, self.world):
                     self.r.unpack_shard(src, self.recv[src].data_ptr())
+        self.last_timing = {"parts": 1, "pack_ms": 0.0, "gather_wait_ms": (t1 - t0) * 1e3, "unpack_ms": (time.perf_counter() - t1) * 1e3}

@@ -67,3 +67,23 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.NativeLibraryError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_runtime_preload_checks_the_soname(tmp_path):
+    """_lib preloads the torch wheel's HIP runtime only if its SONAME is one libmoonrt.so asks for (DT_NEEDED): read from the
+    ELF files themselves."""
+    from moonrtx_amd import _lib, build
+    build.build_native()
+    soname, needed = _lib._elf_dynamic_strings(_lib.LIB_PATH)
+    assert soname is None or soname.startswith("libmoonrt")
+    hip = [n for n in needed if n.startswith("libamdhip64.so")]
+    assert len(hip) == 1 and "libstdc++.so.6" in needed
+    import importlib.util, os
+    spec = importlib.util.find_spec("torch")
+    wheel = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.isfile(wheel):
+        assert _lib._elf_dynamic_strings(wheel)[0] == hip[0]        # this image: the wheel's copy may stand in
+    bad = tmp_path / "x.so"
+    bad.write_bytes(b"not an elf file")
+    with pytest.raises(ValueError):
+        _lib._elf_dynamic_strings(str(bad))

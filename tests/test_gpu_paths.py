@@ -168,3 +168,36 @@ def test_two_ranks_with_environment_and_paths(native_lib, rough):
     finally:
         for rt in rts:
             rt.close()
+
+
+def test_no_memory_for_the_records_falls_back_to_in_wave_paths(native_lib, rough, monkeypatch, capfd):
+    """Round-2 advisor finding: a render call must not fail where an identical result exists.  When the hand-over buffers
+    cannot be allocated (test hook MOONRT_TEST_PATH_NOMEM) the frame is rendered with its paths inside the render wave:
+    one launch, the oracle's frame, one line on stderr."""
+    s = named_scene("S1", 96, 64, spp_per_launch=16)
+    s.path_seg_min, s.path_seg_max = 2, 4
+    lin_o, hits_o, st_o = render_oracle(s, rough)
+    monkeypatch.setenv("MOONRT_TEST_PATH_NOMEM", "1")
+    lin, hits, st, _ = render_hip(s, rough, flags=_lib.F_COUNT_STATS, blocks=(1, 1))
+    lin_o2, hits_o2, st_o2 = render_oracle(s, rough, blocks=(1, 1))
+    assert_bit_equal(lin, lin_o2, "fallback radiance"); assert_bit_equal(hits, hits_o2, "fallback hits")
+    assert st["launches"] == 2 and st["paths_ms"] == 0.0
+    assert capfd.readouterr().err.count("keeps its paths inside the render wave") == 1      # said once per context
+
+
+def test_path_stage_launch_parameters_are_validated(native_lib, rough, monkeypatch):
+    """Round-2 advisor finding: tuning values that would silently drop paths are not accepted -- MOONRT_PATH_GRP above 5 (a group
+    must fit the 64 lanes that hold its chunk counts) and MOONRT_PATH_WAVES below 8 x MOONRT_PATH_NSUB (a work counter without
+    a consumer) are ignored by mrtx_create, and the frame is the oracle's."""
+    s = named_scene("S1", 96, 64, spp_per_launch=64)
+    s.path_seg_min, s.path_seg_max = 2, 4
+    lin_o, hits_o, _ = render_oracle(s, rough)
+    for env in ({"MOONRT_PATH_GRP": "9"}, {"MOONRT_PATH_WAVES": "8"}, {"MOONRT_PATH_WAVES": "16", "MOONRT_PATH_NSUB": "4"},
+                {"MOONRT_PATH_GRP": "5", "MOONRT_PATH_WAVES": "64", "MOONRT_PATH_NSUB": "8"}):
+        for k in ("MOONRT_PATH_GRP", "MOONRT_PATH_WAVES", "MOONRT_PATH_NSUB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        lin, hits, st, _ = render_hip(s, rough, flags=0)
+        assert_bit_equal(lin, lin_o, f"radiance with {env}"); assert_bit_equal(hits, hits_o, f"hits with {env}")
+        assert st["launches"] == 3

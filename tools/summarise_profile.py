@@ -28,11 +28,14 @@ rows = []
 if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(ks[0])))
-avg_ms = {}
+avg_ms, full_name = {}, {}
 for r in rows:
     s = short(r["Name"])
     if s:
+        if s in full_name and full_name[s] != r["Name"]:
+            print(f"WARNING: two production instantiations of {s} in one profile: {full_name[s]} and {r['Name']}; profile one workload at a time")
         avg_ms[s] = float(r["AverageNs"]) / 1e6
+        full_name[s] = r["Name"]           # bench.py accepts the counters only for exactly this instantiation
 pmc = collections.defaultdict(lambda: collections.OrderedDict())
 disp = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
@@ -73,7 +76,7 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
         for k, v in pmc[s].items():
             o.write(f"| {k} | {m[k]:.6g} | {len(v)} |\n")
         o.write(f"\nDispatch: {json.dumps(disp.get(s))}\n\nDerived:\n\n")
-        k = {"avg_ms": round(avg_ms.get(s, 0.0), 4)}
+        k = {"avg_ms": round(avg_ms.get(s, 0.0), 4), "name": full_name.get(s)}
         if "FETCH_SIZE" in m and factor is not None:
             k["hbm_read_bytes"] = m["FETCH_SIZE"] * 1024.0 * factor
             k["hbm_write_bytes"] = m.get("WRITE_SIZE", 0.0) * 1024.0
