@@ -20,3 +20,14 @@ def build_native(force=False):
     if force or stale():
         subprocess.check_call(["make", "-C", CSRC, "-s", "all"])
     return LIB
+
+
+SPILL_LIB = os.path.join(_HERE, "libmoonrt_spilltest.so")
+
+
+def build_spilltest(force=False):
+    """The TEST build of the heavily spilled in-wave counting kernel (see csrc/Makefile, tools/spill_repro.py); the product
+    never loads it.  Built in-tree so that it travels to the GPU box with the snapshot."""
+    if force or not os.path.isfile(SPILL_LIB) or any(os.path.getmtime(os.path.join(CSRC, s)) > os.path.getmtime(SPILL_LIB) for s in SOURCES):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "spilltest"])
+    return SPILL_LIB

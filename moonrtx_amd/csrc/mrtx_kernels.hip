@@ -983,6 +983,53 @@ __device__ __forceinline__ void fused_first_segment(const FrameC& f, MarchState&
 
 #endif   // MRTX_FUSED_TRIAL == 1
 
+// ---- MODE 3 (sky-only tiles, environment map bound): the pixel-uniform shortcut.
+// A 4K pixel of the default view subtends 1/11 of a texel of the reference's 16k star map, so the 64 samples of most sky pixels
+// read ONE texel.  env_rowcol() evaluates the (row, col) a sample at image-plane position (fx, fy) gets -- the very arithmetic of
+// trace_sample + env_lookup up to the floor -- and sky_pixel_uniform() does that at the four corners of a pixel (every jittered
+// position fx = x + u0 lies in [x, x + 1], corners included): when the corners' coordinates, widened by a margin that covers the
+// rounding of the per-sample evaluation (~1.6e-7 x map width texels) and the curvature of the mapping inside the pixel
+// (<= tan(el) theta_px^2, < 2e-3 texels away from the poles, where the corners disagree anyway), all fall into one texel away
+// from the map's seam and edges, every sample of the pixel reads that texel.  The S samples of a block then add up to S x texel
+// exactly (a pairwise tree over S equal floats), so the pixel needs one look-up instead of S.  Result-preserving: radiance and
+// counters equal the per-sample evaluation (tests/test_gpu_paths.py, the fuzz's environment cases).
+__device__ __forceinline__ void env_rowcol(const FrameC& f, float fx, float fy, float& rowf, float& colf) {
+    const float sx = fmaf(fx, CF(f)->two_over_w, -1.0f);
+    const float sy = fmaf(-fy, CF(f)->two_over_h, 1.0f);
+    float dx = fmaf(sy, CF(f)->Vy[0], fmaf(sx, CF(f)->Ux[0], CF(f)->Wd[0]));
+    float dy = fmaf(sy, CF(f)->Vy[1], fmaf(sx, CF(f)->Ux[1], CF(f)->Wd[1]));
+    float dz = fmaf(sy, CF(f)->Vy[2], fmaf(sx, CF(f)->Ux[2], CF(f)->Wd[2]));
+    const float inv_len = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    dx = dx * inv_len; dy = dy * inv_len; dz = dz * inv_len;
+    float el, az;
+    latlon(dx, dy, dz, fmaf(dy, dy, dx * dx), el, az);
+    rowf = fmaf(el, CF(f)->bg_row_scale, CF(f)->bg_row_off);
+    colf = fmaf(az, CF(f)->bg_col_scale, CF(f)->bg_col_off);
+}
+__device__ __forceinline__ bool sky_pixel_uniform(const FrameC& f, int x, int y, float& e0, float& e1, float& e2) {
+    float r00, c00, r10, c10, r01, c01, r11, c11;
+    const float fx = (float)x, fy = (float)y;
+    env_rowcol(f, fx, fy, r00, c00);
+    env_rowcol(f, fx + 1.0f, fy, r10, c10);
+    env_rowcol(f, fx, fy + 1.0f, r01, c01);
+    env_rowcol(f, fx + 1.0f, fy + 1.0f, r11, c11);
+    const float m = fmaf(1.0e-6f, (float)max(CF(f)->bg_w, CF(f)->bg_h), 0.02f);
+    const float rlo = fminf(fminf(r00, r10), fminf(r01, r11)) - m, rhi = fmaxf(fmaxf(r00, r10), fmaxf(r01, r11)) + m;
+    const float clo = fminf(fminf(c00, c10), fminf(c01, c11)) - m, chi = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) + m;
+    const float rf = floorf(rlo), cf = floorf(clo);
+    // one texel, no clamp (rows), no wrap (columns); NaNs compare false
+    const bool uni = rf == floorf(rhi) && cf == floorf(chi) && rlo >= 0.0f && clo >= 0.0f &&
+                     rhi < (float)CF(f)->bg_h && chi < (float)CF(f)->bg_w;
+    e0 = e1 = e2 = 0.0f;
+    if (uni) {
+        const uint32_t px = reinterpret_cast<const uint32_t*>(CF(f)->bg)[(int64_t)(int)rf * CF(f)->bg_w + (int)cf];
+        e0 = (float)(px & 255u) * kInv255;
+        e1 = (float)((px >> 8) & 255u) * kInv255;
+        e2 = (float)((px >> 16) & 255u) * kInv255;
+    }
+    return uni;
+}
+
 struct SampleOut {
     float c0, c1, c2, hitflag;
     float h0, h1, h2, h3;
@@ -1332,12 +1379,15 @@ __device__ __forceinline__ float tree_sum(float v) {
 #ifndef MRTX_BOUNCE_STATS_WAVES
 #define MRTX_BOUNCE_STATS_WAVES 2   // tools/spill_repro.py builds with 7 to bring the spilled configuration back
 #endif
-#define MRTX_BOUNCE_WAVES(STATS) ((STATS) ? MRTX_BOUNCE_STATS_WAVES : MRTX_MIN_WAVES_BOUNCE)
+// The in-wave path kernels that actually ship are the preview launches (1 / 2 samples per pixel; launches below ~8 M samples keep
+// their paths in the wave): at 4 waves per SIMD they need no scratch and run as fast (4K, 1 spp: 1.302 ms against 1.312 with
+// 17 spilled registers at 5 waves; 2 spp 2.256 / 2.270); the larger S (an A/B path and the no-memory fall-back) keep 5.
+#define MRTX_BOUNCE_WAVES(STATS, SV) ((STATS) ? MRTX_BOUNCE_STATS_WAVES : ((SV) <= 2 ? 4 : MRTX_MIN_WAVES_BOUNCE))
 template <int S, bool STATS, bool WIDE, int MODE, bool OVERLAY>
 #ifndef MRTX_MIN_WAVES_DEFER
 #define MRTX_MIN_WAVES_DEFER 3   // 15.3 ms at cfg3 against 17.1 with 4 and 19.3 with 5 (hand-over stores + cache footprint)
 #endif
-__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MODE == 1 ? MRTX_BOUNCE_WAVES(STATS) : MODE == 2 ? MRTX_MIN_WAVES_DEFER : MRTX_MIN_WAVES)
+__global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MODE == 1 ? MRTX_BOUNCE_WAVES(STATS, S) : MODE == 2 ? MRTX_MIN_WAVES_DEFER : MRTX_MIN_WAVES)
 render_kernel(const FrameC f, const PathQ pq) {
     constexpr bool DEFER = MODE == 2;
     constexpr int P = 64 / S;
@@ -1397,6 +1447,12 @@ render_kernel(const FrameC f, const PathQ pq) {
     }
 
     const int p = lane / S, s = lane % S;
+    // MODE 3: lane l looks at pixel (l % 8, l / 8) of the wave's 8 x 8 block first -- one texel for the whole pixel? (see
+    // sky_pixel_uniform) -- and the jobs below take a pixel's verdict and texel from the lane that holds them
+    constexpr bool SKY_UNI = MODE == 3 && WGT == 8 && MRTX_WG_WAVES == 1;
+    bool sky_uni = false;
+    float sky0 = 0.0f, sky1 = 0.0f, sky2 = 0.0f;
+    if (SKY_UNI && CF(f)->bg != nullptr) sky_uni = sky_pixel_uniform(f, px0 + (lane & 7), py0 + (lane >> 3), sky0, sky1, sky2);
     for (int job = wv; job < NJOBS; job += MRTX_WG_WAVES) {
         const int jx = job % JX, jy = job / JX;
         const int x = px0 + jx * PW + (p % PW), y = py0 + jy * PH + (p / PW);
@@ -1411,7 +1467,20 @@ render_kernel(const FrameC f, const PathQ pq) {
         for (uint32_t blk = 0; blk < f.n_blocks; blk++) {   // DEFER launches carry one block each
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
             PROF_BEGIN(0);
-            if (inb) trace_sample<STATS, WIDE, MODE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            bool traced = false;
+            if (SKY_UNI) {
+                // every pixel of this job reads one texel: the S samples of a pixel are S copies of it (tree_sum over S equal
+                // values is S x value exactly, as the per-sample evaluation gives)
+                const int pl = ((jy * PH + (p / PW)) << 3) + jx * PW + (p % PW);
+                const bool u = __shfl((int)sky_uni, pl, 64) != 0;
+                const float v0 = __shfl(sky0, pl, 64), v1 = __shfl(sky1, pl, 64), v2 = __shfl(sky2, pl, 64);
+                if (__ballot(inb && !u) == 0ull) {
+                    o.c0 = inb ? v0 : 0.0f; o.c1 = inb ? v1 : 0.0f; o.c2 = inb ? v2 : 0.0f;
+                    if (STATS && inb) { cnt[ST_PRIMARY]++; cnt[ST_BG]++; }
+                    traced = true;
+                }
+            }
+            if (inb && !traced) trace_sample<STATS, WIDE, MODE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
             PROF_END(0);
             if (blk == 0 && f.first_block != 0 && inb && s == 0) {
                 // the running sums of earlier launches are fetched HERE, not before the first block was traced (four registers

@@ -115,7 +115,8 @@ def host_inputs(inputs):
 
 
 # 64x48 crops of the cfg3 frame: across the terminator, the lit limb with sky beside it, the disc centre, the dark limb
-HEADLINE_CROPS = ((1500, 1000), (2860, 1060), (1888, 1056), (930, 1300))
+# ... and a piece of pure sky (black without an environment map; with the star map: render_kernel<MODE 3> and its one-texel-per-pixel shortcut)
+HEADLINE_CROPS = ((1500, 1000), (2860, 1060), (1888, 1056), (930, 1300), (96, 64))
 
 
 def headline_scene():

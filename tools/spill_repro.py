@@ -5,6 +5,7 @@ Round 1: with a 72-VGPR cap the instantiation render_kerne
 (~290 spilled VGPRs) miscomputed one sample; the counting variants were then given a 2-waves launch bound and the case
 was not kept.  This script brings the configuration back -- build with
     tools/build_variant.sh spill -DMRTX_BOUNCE_STATS_WAVES=7 -DMRTX_MIN_WAVES_BOUNCE=7
+(or `make -C moonrtx_amd/csrc spilltest` -> moonrtx_amd/libmoonrt_spilltest.so, which the GPU suite uses)
 -- and runs every fuzz case through exactly that instantiation (S = 64, counters on, paths in the wave, overlay tubes,
 32-bit DEM offsets) against the oracle, printing every mismatch with its first differing pixel.
 usage: MOONRT_LIB=ab/libmoonrt_spill.so python tools/spill_repro.py [n_cases] [seed]"""
@@ -43,3 +44,4 @@ for k, c in enumerate(itertools.islice(fuzz_cases.cases(seed), n)):
     elif k % 25 == 0:
         print("ok", k, flush=True)
 print(f"{n} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
