@@ -1450,13 +1450,37 @@ render_kernel(const FrameC f, const PathQ pq) {
     // MODE 3: lane l looks at pixel (l % 8, l / 8) of the wave's 8 x 8 block first -- one texel for the whole pixel? (see
     // sky_pixel_uniform) -- and the jobs below take a pixel's verdict and texel from the lane that holds them
     constexpr bool SKY_UNI = MODE == 3 && WGT == 8 && MRTX_WG_WAVES == 1;
-    bool sky_uni = false;
-    float sky0 = 0.0f, sky1 = 0.0f, sky2 = 0.0f;
-    if (SKY_UNI && CF(f)->bg != nullptr) sky_uni = sky_pixel_uniform(f, px0 + (lane & 7), py0 + (lane >> 3), sky0, sky1, sky2);
+    uint64_t sky_nu = ~0ull;             // lanes (= pixels of the 8 x 8 block) whose samples do NOT all read one texel
+    auto sky_jobmask = [&](int jx_, int jy_) {   // the lanes that hold the PW x PH pixels of job (jx_, jy_)
+        uint64_t mk = 0ull;
+#pragma unroll
+        for (int r = 0; r < PH; r++) mk |= (uint64_t)((1u << PW) - 1u) << ((jy_ * PH + r) * 8 + jx_ * PW);
+        return mk;
+    };
+    if (SKY_UNI && CF(f)->bg != nullptr) {
+        // lane l = pixel (l % 8, l / 8): a pixel whose whole job is uniform is finished right here, one lane per pixel -- per
+        // block the S samples add up to S x texel exactly (the tree sum of S equal values), blocks in sequence as always
+        const int ux = px0 + (lane & 7), uy = py0 + (lane >> 3);
+        const bool uin = ux < f.W && uy < f.H;
+        float sky0, sky1, sky2;
+        const bool uni = sky_pixel_uniform(f, ux, uy, sky0, sky1, sky2);
+        sky_nu = __ballot(uin && !uni);
+        if (uin && (sky_nu & sky_jobmask((lane & 7) / PW, (lane >> 3) / PH)) == 0ull) {
+            const int64_t upix = (int64_t)uy * f.W + ux;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f.first_block != 0) a = reinterpret_cast<const float4*>(CF(f)->accum)[upix];
+            const float b0 = (float)S * sky0, b1 = (float)S * sky1, b2 = (float)S * sky2;
+            for (uint32_t blk = 0; blk < f.n_blocks; blk++) { a.x += b0; a.y += b1; a.z += b2; a.w += 0.0f; }
+            reinterpret_cast<float4*>(CF(f)->accum)[upix] = a;
+            reinterpret_cast<float4*>(CF(f)->hits)[upix] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (STATS) { cnt[ST_PRIMARY] += (uint32_t)S * f.n_blocks; cnt[ST_BG] += (uint32_t)S * f.n_blocks; }
+        }
+    }
     for (int job = wv; job < NJOBS; job += MRTX_WG_WAVES) {
         const int jx = job % JX, jy = job / JX;
         const int x = px0 + jx * PW + (p % PW), y = py0 + jy * PH + (p / PW);
         if (px0 + jx * PW >= f.W || py0 + jy * PH >= f.H) continue;  // wave-uniform
+        if (SKY_UNI && (sky_nu & sky_jobmask(jx, jy)) == 0ull) continue;   // every pixel of the job was finished above
         const bool inb = x < f.W && y < f.H;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         SampleOut o;
@@ -1467,20 +1491,7 @@ render_kernel(const FrameC f, const PathQ pq) {
         for (uint32_t blk = 0; blk < f.n_blocks; blk++) {   // DEFER launches carry one block each
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
             PROF_BEGIN(0);
-            bool traced = false;
-            if (SKY_UNI) {
-                // every pixel of this job reads one texel: the S samples of a pixel are S copies of it (tree_sum over S equal
-                // values is S x value exactly, as the per-sample evaluation gives)
-                const int pl = ((jy * PH + (p / PW)) << 3) + jx * PW + (p % PW);
-                const bool u = __shfl((int)sky_uni, pl, 64) != 0;
-                const float v0 = __shfl(sky0, pl, 64), v1 = __shfl(sky1, pl, 64), v2 = __shfl(sky2, pl, 64);
-                if (__ballot(inb && !u) == 0ull) {
-                    o.c0 = inb ? v0 : 0.0f; o.c1 = inb ? v1 : 0.0f; o.c2 = inb ? v2 : 0.0f;
-                    if (STATS && inb) { cnt[ST_PRIMARY]++; cnt[ST_BG]++; }
-                    traced = true;
-                }
-            }
-            if (inb && !traced) trace_sample<STATS, WIDE, MODE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            if (inb) trace_sample<STATS, WIDE, MODE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
             PROF_END(0);
             if (blk == 0 && f.first_block != 0 && inb && s == 0) {
                 // the running sums of earlier launches are fetched HERE, not before the first block was traced (four registers
