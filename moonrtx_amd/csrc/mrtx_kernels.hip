@@ -167,7 +167,14 @@ struct __attribute__((packed, aligned(4))) Pair { float x, y; };
 struct __attribute__((packed, aligned(8))) Quad { float a, b, c, d; };
 struct __attribute__((packed, aligned(8))) UQuad { uint32_t a, b, c, d; };
 
-template <bool WIDE>
+// CP: cache policy of the load -- 0 plain, 1 non-temporal (a line the wave will not touch again: the incoherent marches)
+#ifndef MRTX_TRIAL_CP
+#define MRTX_TRIAL_CP 0
+#endif
+#ifndef MRTX_PATH_CP
+#define MRTX_PATH_CP 0
+#endif
+template <bool WIDE, int CP = 0>
 __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float colf) {
     const float rfl = floorf(rowf), cfl = floorf(colf);
     const float fr = rowf - rfl, fc = colf - cfl;
@@ -180,7 +187,10 @@ __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float co
     // row-pair layout: element (r, c) = (D[r][c], D[r+1][c]); elements (r0, c0) and (r0, c0+1) are adjacent, so the
     // whole 2x2 footprint is ONE 16-byte load -- half the gather instructions and L1 tag look-ups of two row loads
     Quad q;
-    if (WIDE) q = *reinterpret_cast<const Quad*>(base + ((uint64_t)idx << 3));
+    if (CP == 1) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(WIDE ? base + ((uint64_t)idx << 3) : base + (idx << 3)));
+        q.a = v.x; q.b = v.y; q.c = v.z; q.d = v.w;
+    } else if (WIDE) q = *reinterpret_cast<const Quad*>(base + ((uint64_t)idx << 3));
     else q = *reinterpret_cast<const Quad*>(base + (idx << 3));
     return lerp2(q.a, q.c, q.b, q.d, fr, fc);
 #else
@@ -309,7 +319,7 @@ __device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, f
 // EXACTABLE = false: the caller knows (by ballot) that no lane of the wave is in an exact-fallback segment.
 // The quadratic needs no clamp: a non-seam, non-polar segment keeps (row, col) >= 0.5 texel inside
 // [-1, h) x [-1, w), and dem_march()'s unsigned index clamp keeps even a NaN inside the allocation.
-template <bool WIDE, bool EXACTABLE>
+template <bool WIDE, bool EXACTABLE, int CP = 0>
 __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float sk, float pa, float pb, float pc,
                                           float r2) {
     const float u = (sk - sg.sa) * f.inv_step;
@@ -319,7 +329,7 @@ __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float 
         float q2;
         exact_rowcol(f, pa, pb, pc, rowf, colf, q2);
     }
-    const float surf = f.Rf * dem_march<WIDE>(f, rowf, colf);
+    const float surf = f.Rf * dem_march<WIDE, CP>(f, rowf, colf);
     return r2 <= surf * surf;
 }
 
@@ -338,7 +348,7 @@ __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float 
 #ifndef MRTX_STEP_BATCH_BOUNCE
 #define MRTX_STEP_BATCH_BOUNCE 1
 #endif
-template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE, int BATCH>
+template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE, int BATCH, int CP = 0>
 __device__ __forceinline__ void step_loop_from(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                                float smax, const Seg& sg, int ka, int j, bool more, bool& go, bool& hit,
                                                float& sk_out, uint32_t* cnt) {
@@ -349,7 +359,7 @@ __device__ __forceinline__ void step_loop_from(const FrameC& f, float oa, float 
             const float pa = fmaf(sk, da, oa), pb = fmaf(sk, db, ob), pc = fmaf(sk, dc, oc);
             const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
             const bool in = (PRIMARY ? (sk <= smax) : (r2 <= f.R2f)) & (k <= f.kmax);
-            const bool bel = below_seg<WIDE, EXACTABLE>(f, sg, sk, pa, pb, pc, r2);
+            const bool bel = below_seg<WIDE, EXACTABLE, CP>(f, sg, sk, pa, pb, pc, r2);
             if (STATS) { cnt[ST_HEIGHT] += in ? 1u : 0u; cnt[ST_FETCH]++; }
 #ifdef MRTX_PROF
             cnt[11] += 1;                                    // wave-level step iterations
@@ -371,7 +381,7 @@ __device__ __forceinline__ void step_loop_from(const FrameC& f, float oa, float 
                 const float u = ((float)(ka + min(j + i, SEG_N)) * f.step - sg.sa) * f.inv_step;   // as below_seg()
                 const float rowf = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra);
                 const float colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
-                surf[i] = f.Rf * dem_march<WIDE>(f, rowf, colf);
+                surf[i] = f.Rf * dem_march<WIDE, CP>(f, rowf, colf);
             }
 #ifdef MRTX_PROF
             cnt[11] += 1;
@@ -398,11 +408,11 @@ __device__ __forceinline__ void step_loop_from(const FrameC& f, float oa, float 
     }
 }
 
-template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE, int BATCH>
+template <bool WIDE, bool PRIMARY, bool STATS, bool EXACTABLE, int BATCH, int CP = 0>
 __device__ __forceinline__ void step_loop(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                           float smax, const Seg& sg, int ka, bool& go, bool& hit, float& sk_out,
                                           uint32_t* cnt) {
-    step_loop_from<WIDE, PRIMARY, STATS, EXACTABLE, BATCH>(f, oa, ob, oc, da, db, dc, smax, sg, ka, sg.jlo, sg.jlo <= sg.jhi,
+    step_loop_from<WIDE, PRIMARY, STATS, EXACTABLE, BATCH, CP>(f, oa, ob, oc, da, db, dc, smax, sg, ka, sg.jlo, sg.jlo <= sg.jhi,
                                                            go, hit, sk_out, cnt);
 }
 
@@ -558,7 +568,7 @@ __device__ __forceinline__ void segment_tail(const FrameC& f, MarchState& m, flo
 // ONE 16-step segment of a march (the lanes that call it are still marching): anchors + skip interval, the steps
 // that can be at/below the surface, the termination test at the segment end.  `hit` / `sk_hit` are set by the step
 // that lands at/below the surface, `go` says whether the ray continues with the next segment.
-template <bool WIDE, bool PRIMARY, bool STATS, int BATCH>
+template <bool WIDE, bool PRIMARY, bool STATS, int BATCH, int CP = 0>
 __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, float smax, Seg& sg, bool& go, bool& hit,
                                               float& sk_hit, uint32_t* cnt) {
     const float oa = m.oa, ob = m.ob, oc = m.oc, da = m.da, db = m.db, dc = m.dc;
@@ -571,9 +581,9 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
     PROF_BEGIN(7);
     if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, 1, sg.jlo - 1);
     if (__ballot(sg.exact) != 0ull)
-        step_loop<WIDE, PRIMARY, STATS, true, 1>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+        step_loop<WIDE, PRIMARY, STATS, true, 1, CP>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
     else
-        step_loop<WIDE, PRIMARY, STATS, false, BATCH>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
+        step_loop<WIDE, PRIMARY, STATS, false, BATCH, CP>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
     PROF_END(7);
 #ifdef MRTX_PROF
 #if !defined(MRTX_PROF_SPREAD) && !defined(MRTX_PROF_TRIAL)
@@ -1293,7 +1303,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 bool tgo = march_begin_at<false, STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, tm, tcnt), thit = false;
                 Seg tsg;
                 float tsk = 0.0f;
-                if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
+                if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH, MRTX_TRIAL_CP>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
 #ifdef MRTX_PROF_TRIAL   // measurement only: the trial's step iterations and the lanes evaluating in them (slots 13 / 14), its cycles (15)
                 cnt[13] += tcnt[11]; cnt[14] += tcnt[12]; cnt[15] += tcnt[6] + tcnt[7];
 #endif
@@ -1798,7 +1808,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                     const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
                     const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
                     in[i] = (r2 <= f.R2f) & (k <= f.kmax);
-                    bel[i] = below_seg<WIDE, true>(f, sg, sk, pa, pb, pc, r2);
+                    bel[i] = below_seg<WIDE, true, MRTX_PATH_CP>(f, sg, sk, pa, pb, pc, r2);
                     sks[i] = sk;
                 }
                 bool act = !bis;
