@@ -95,12 +95,19 @@ class FrameGather:
 
     def render_and_gather(self, n_blocks=1, parts=None):
         """One block of samples on every rank + the exchange, overlapped: the tile list renders in `parts` pieces
-        (default MOONRT_GATHER_PARTS or 2) and the RCCL gather of piece k runs on the collective's stream while
+        (MOONRT_GATHER_PARTS, default: two pieces when a rank's shard is 32 MB or more, else one) and the RCCL gather of piece k
+        runs on the collective's stream while
         piece k+1 renders.  Falls back to render() + gather() when the scene needs the full layout, on a single
         rank, and with host-staged (gloo) transport.  Returns the summed render statistics."""
         r = self.r
         if parts is None:
-            parts = int(os.environ.get("MOONRT_GATHER_PARTS", "2"))
+            parts = int(os.environ.get("MOONRT_GATHER_PARTS", "0"))
+        if parts <= 0:
+            # A part costs a render + path-stage + resolve launch of its own: +0.3 ms per rank at cfg3 (one GPU, rank after rank:
+            # world 8 4.03 ms in two parts against 3.58 in one, world 2 12.96 / 12.73; profiles/r03_rank_balance.md), and hides the
+            # exchange of the OTHER part.  That pays only while half a shard takes longer than that over one xGMI link
+            # (~50 GB/s assumed, unmeasured here): two parts from 32 MB per rank up (cfg3: world 2), one below (world 4, 8).
+            parts = 2 if (self.world > 1 and hasattr(r, "shard_bytes_active") and r.shard_bytes_active() >= (32 << 20)) else 1
         P = r.shard_parts(parts) if (self.world > 1 and parts > 1 and hasattr(r, "shard_parts") and not self.host_staged) else 1
         if P == 1:
             st = r.render(n_blocks)

@@ -191,6 +191,16 @@ def check_case(c):
         assert_bit_equal(hits_h, hits_o, desc + ": sharded hits")
         return st_o
     lin_h, hits_h, st_h, img_h = render_hip(s, dem, col, bg, blocks=blocks, tile=tile, flags=flags, capsules=caps)
+    if not np.array_equal(lin_h.view(np.uint32), lin_o.view(np.uint32)):
+        # evidence for a mismatch that does not repeat (round 3: seed 601 case 49 failed once in a 300-case run and passed alone
+        # and in the same sequence afterwards): render both sides again and say which one moved
+        lin_h2 = render_hip(s, dem, col, bg, blocks=blocks, tile=tile, flags=flags, capsules=caps)[0]
+        lin_o2 = render_oracle(s, dem, col, bg, blocks=blocks, capsules=caps)[0]
+        bad = np.argwhere((lin_h.view(np.uint32) != lin_o.view(np.uint32)).any(axis=2))
+        desc += (f" [again: HIP repeats itself {np.array_equal(lin_h2.view(np.uint32), lin_h.view(np.uint32))}, oracle repeats itself "
+                 f"{np.array_equal(lin_o2.view(np.uint32), lin_o.view(np.uint32))}, second HIP run equals the oracle "
+                 f"{np.array_equal(lin_h2.view(np.uint32), lin_o.view(np.uint32))}; flags {flags}; {len(bad)} pixels, x {bad[:, 1].min()}..{bad[:, 1].max()}, "
+                 f"y {bad[:, 0].min()}..{bad[:, 0].max()}]")
     assert_bit_equal(lin_h, lin_o, desc + ": radiance")
     assert_bit_equal(hits_h, hits_o, desc + ": hits")
     assert np.array_equal(img_h, img_o), desc + ": tone-mapped RGBA8 image"

@@ -24,12 +24,19 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         rt.set_params(flags=int(os.environ.get("MRTX_FLAGS", "0")))
         rt.reset(); rt.render(1)
         t = []
+        P = rt.shard_parts(int(os.environ.get("PARTS", "1"))) if world > 1 else 1     # PARTS=2: as FrameGather.render_and_gather drives it
         for _ in range(3):
-            rt.reset(); st = rt.render(1); t.append((st["kernel_ms"], st["primary_ms"], st["paths_ms"]))
+            rt.reset()
+            if P > 1:
+                sts = [rt.render_part(1, k, P) for k in range(P)]
+                st = {key: sum(s_[key] for s_ in sts) for key in ("kernel_ms", "primary_ms", "paths_ms")}
+            else:
+                st = rt.render(1)
+            t.append((st["kernel_ms"], st["primary_ms"], st["paths_ms"]))
         ms.append(min(t)[0]); split.append(min(t)[1:])
         nbytes = rt.shard_bytes_active() if world > 1 else 0
         full = rt.shard_bytes()
         rt.close()
-    print(f"world {world}: kernel ms per rank min {min(ms):.3f} mean {sum(ms) / len(ms):.3f} max {max(ms):.3f} "
+    print(f"world {world} ({P} part(s)): kernel ms per rank min {min(ms):.3f} mean {sum(ms) / len(ms):.3f} max {max(ms):.3f} "
           f"(imbalance {max(ms) / (sum(ms) / len(ms)) - 1:.1%}); sum {sum(ms):.2f}; shard {nbytes / 1e6:.1f} MB active of {full / 1e6:.1f} MB; "
           f"slowest rank: render {max(split)[0]:.3f} + paths {max(split)[1]:.3f}")
