@@ -900,8 +900,13 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     for (int s = 0; mode == 2 && s < n_sub; s++) {
         PathQ& pq = pqs[(size_t)s];
         pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
-        pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n;
+#if MRTX_C_AOS
+        pq.c4 = pq.ray2 + n; pq.c0 = pq.c1 = pq.c2 = nullptr;
+        pq.lane_of = reinterpret_cast<uint32_t*>(pq.c4 + n);
+#else
+        pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n; pq.c4 = nullptr;
         pq.lane_of = reinterpret_cast<uint32_t*>(pq.c2 + n);
+#endif
         pq.npaths = c->path_npaths;
         pq.meta = c->path_meta;
         pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
@@ -996,6 +1001,8 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             out->primary_hits = h[1]; out->shadow_rays = h[2];
             out->height_samples = h[3]; out->colour_fetches = h[4]; out->background_fetches = h[5];
             out->dem_fetches = h[6]; out->mip_fetches = h[7]; out->bounce_rays = h[8]; out->bounce_sun_hits = h[9];
+            if (std::getenv("MOONRT_DEBUG_STATS"))   // measurement builds (-DMRTX_PROF_MARGIN): the spare counter slots
+                std::fprintf(stderr, "libmoonrt debug stats[10..14]: %llu %llu %llu %llu %llu\n", h[10], h[11], h[12], h[13], h[14]);
         }
     }
     return MRTX_OK;

@@ -117,7 +117,7 @@ struct FrameC {
 //             out about the ray: bit 6 = still marching after segment 1 (bits 8-31 = its horizon bound kend, the texel
 //             coordinates are those of the END of segment 1), bit 7 = hit inside segment 1 (bits 8-31 = the step k that
 //             landed at/below the surface, the coordinates are the origin's); neither = march from the origin
-//   c0/1/2    the sample's radiance so far (direct term / Sun disk / environment / overlay colour); path_kernel writes
+//   c4 (c0/1/2 with MRTX_C_AOS = 0)  the sample's radiance so far (direct term / Sun disk / environment / overlay colour); path_kernel writes
 //             the final value back when the path adds light, resolve_paths_kernel sums the 64 lanes in the butterfly
 //             order of the spec
 //   meta      per chunk: bit 31 = the chunk was deferred, bits 0-14 / 15-29 = pixel (x0, y0) of the wave's pixel block
@@ -125,6 +125,7 @@ struct FrameC {
 struct PathQ {
     float4* ray0; float4* ray1; float4* ray2;
     float* c0; float* c1; float* c2;
+    float4* c4;                 // MRTX_C_AOS: the three of them as one float4 per sample (one 16-byte access instead of three sectors)
     uint32_t* lane_of;          // per ray record: lane + the state of its march after the trial segment (see above)
     uint8_t* npaths;            // per chunk: ray records it holds (0 for a chunk that was not deferred): zero before the launch
     uint32_t* meta;
@@ -140,6 +141,11 @@ struct PathQ {
     int32_t rare_min;           // ... and runs the rare steps (a continuation ray hit terrain; a vertex got its direct
                                 //     term) when at least this many lanes wait for them
 };
-#define MRTX_PATH_REC_BYTES 64  // per record: 3 x float4 + 3 x float + 1 word
+// The running radiance of a sample as ONE float4 per sample (round 3): a path that adds light reads and writes one 64-byte sector
+// instead of three in three arrays -- path stage 5.41 -> 5.19 ms at cfg3, render and resolve unchanged (0 = the three float arrays)
+#ifndef MRTX_C_AOS
+#define MRTX_C_AOS 1
+#endif
+#define MRTX_PATH_REC_BYTES (MRTX_C_AOS ? 68 : 64)  // per record: 3 x float4 + 3 x float (or one float4) + 1 word
 #define MRTX_REC_RESUME 64u
 #define MRTX_REC_HIT 128u

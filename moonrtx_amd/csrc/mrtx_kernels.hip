@@ -54,7 +54,11 @@ __device__ unsigned long long g_prof[16];
 #define PROF_END(i)
 #endif
 
+#ifdef MRTX_PROF_MARGIN   // measurement build: how far above the surface are the steps path_kernel evaluates? (slots 10-13 of stats[])
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_FETCH, ST_MIP, ST_BOUNCE, ST_SUNHIT, ST_MALL, ST_M1, ST_M2, ST_M3, ST_N };
+#else
 enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_HEIGHT, ST_COLOUR, ST_BG, ST_FETCH, ST_MIP, ST_BOUNCE, ST_SUNHIT, ST_N };
+#endif
 
 // atan(q) ~= q * P(q^2) on [0,1], |err| <= 1.3e-7
 __device__ __forceinline__ float atan_poly(float q) {
@@ -163,6 +167,21 @@ __device__ __forceinline__ float4 nt_load4(const float4* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// a sample's running radiance in the hand-over buffers (PathQ::c0/c1/c2, or one float4 per sample with MRTX_C_AOS)
+__device__ __forceinline__ void c_load(const PathQ& pq, uint32_t e, float& c0, float& c1, float& c2) {
+#if MRTX_C_AOS
+    const float4 v = pq.c4[e]; c0 = v.x; c1 = v.y; c2 = v.z;
+#else
+    c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e];
+#endif
+}
+__device__ __forceinline__ void c_store(const PathQ& pq, uint32_t e, float c0, float c1, float c2) {
+#if MRTX_C_AOS
+    pq.c4[e] = make_float4(c0, c1, c2, 0.0f);
+#else
+    pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2;
+#endif
+}
 struct __attribute__((packed, aligned(4))) Pair { float x, y; };
 struct __attribute__((packed, aligned(8))) Quad { float a, b, c, d; };
 struct __attribute__((packed, aligned(8))) UQuad { uint32_t a, b, c, d; };
@@ -1526,9 +1545,13 @@ render_kernel(const FrameC f, const PathQ pq) {
                     nt_store4(pq.ray2 + es, o.t2, o.row, o.col, __uint_as_float(o.ks));
                     pq.lane_of[es] = (uint32_t)lane | o.aux;
                 }
+#if MRTX_C_AOS
+                nt_store4(pq.c4 + e, o.c0, o.c1, o.c2, 0.0f);
+#else
                 __builtin_nontemporal_store(o.c0, pq.c0 + e);
                 __builtin_nontemporal_store(o.c1, pq.c1 + e);
                 __builtin_nontemporal_store(o.c2, pq.c2 + e);
+#endif
 #endif
                 if (lane == 0) pq.npaths[chunk] = (uint8_t)__popcll(pm);
                 if (lane == 0) pq.meta[chunk] = 0x80000000u | (uint32_t)(px0 + jx * PW) | ((uint32_t)(py0 + jy * PH) << 15);
@@ -1800,6 +1823,9 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 const bool bis = state == PS_BISECT;
                 bool bel[MRTX_PATH_STEPS], in[MRTX_PATH_STEPS];
                 float sks[MRTX_PATH_STEPS];
+#ifdef MRTX_PROF_MARGIN
+                float mrg[MRTX_PATH_STEPS];
+#endif
                 const float mid0 = 0.5f * (bis_lo + bis_hi);
 #pragma unroll
                 for (int i = 0; i < MRTX_PATH_STEPS; i++) {
@@ -1810,6 +1836,14 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                     in[i] = (r2 <= f.R2f) & (k <= f.kmax);
                     bel[i] = below_seg<WIDE, true, MRTX_PATH_CP>(f, sg, sk, pa, pb, pc, r2);
                     sks[i] = sk;
+#ifdef MRTX_PROF_MARGIN
+                    {
+                        const float uu = (sk - sg.sa) * f.inv_step;
+                        float rw = fmaf(uu, fmaf(uu, sg.r2, sg.r1), sg.ra), cl = fmaf(uu, fmaf(uu, sg.c2, sg.c1), sg.ca);
+                        if (sg.exact) { float q2; exact_rowcol(f, pa, pb, pc, rw, cl, q2); }
+                        mrg[i] = sqrtf(r2) / (f.Rf * dem_march<WIDE>(f, rw, cl)) - 1.0f;
+                    }
+#endif
                 }
                 bool act = !bis;
                 if (bis) {
@@ -1828,6 +1862,9 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 for (int i = 0; i < MRTX_PATH_STEPS; i++) {
                     if (act) {
                         if (STATS) { cnt[ST_HEIGHT] += in[i] ? 1u : 0u; cnt[ST_FETCH]++; }
+#ifdef MRTX_PROF_MARGIN
+                        if (STATS) { cnt[ST_MALL]++; cnt[ST_M1] += mrg[i] > 1.0e-4f; cnt[ST_M2] += mrg[i] > 3.0e-4f; cnt[ST_M3] += mrg[i] > 1.0e-3f; }
+#endif
                         j++;
                         if (in[i] & bel[i]) { hit = true; sk_hit = sks[i]; state = PS_ENDED; act = false; }
                         else if (!in[i]) { state = PS_ENDED; act = false; }
@@ -1861,7 +1898,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             } else if (hit) {
                 // D3: bracket the crossing between the last step above and the first step at/below the surface; the sample's
                 // radiance so far is fetched now, to arrive while the bisection runs
-                if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                if (!have_c) { c_load(pq, e, c0, c1, c2); have_c = true; }
                 const int bk = (int)rintf(sk_hit * f.inv_step);
                 bis_lo = (float)(bk - 1) * f.step;       // bis_hi is sk_hit already
                 j = f.nbis;
@@ -1874,10 +1911,10 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             } else {
                 float e0, e1, e2;
                 if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {   // the Sun disk
-                    if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                    if (!have_c) { c_load(pq, e, c0, c1, c2); have_c = true; }
                     c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
                 }
-                if (have_c) { pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2; }
+                if (have_c) c_store(pq, e, c0, c1, c2);
                 state = PS_IDLE;
             }
         }
@@ -1893,11 +1930,11 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                     // a black texel adds nothing (fmaf(t, 0, c) == c for finite t): the sample's radiance need not be touched
                     const bool nothing = (e0 == 0.0f) & (e1 == 0.0f) & (e2 == 0.0f) & ((t0r + t1r + t2r) < __builtin_inff());
                     if (!nothing) {
-                        if (!have_c) { c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e]; have_c = true; }
+                        if (!have_c) { c_load(pq, e, c0, c1, c2); have_c = true; }
                         c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
                     }
                 }
-                if (have_c) { pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2; }
+                if (have_c) c_store(pq, e, c0, c1, c2);
                 state = PS_IDLE;
             }
             if (state == PS_HITWAIT) {
@@ -1928,7 +1965,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                     hit = false; shadow = false;
                     state = go ? PS_NEEDSEG : PS_ENDED;
                 } else {
-                    pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2;
+                    c_store(pq, e, c0, c1, c2);
                     state = PS_IDLE;
                 }
             }
@@ -1977,9 +2014,13 @@ __global__ void __launch_bounds__(256) resolve_paths_kernel(const FrameC f, cons
             acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (mt[u] & 0x80000000u) {                       // wave-uniform
                 const uint32_t e = (base + u) * 64u + lane;
+#if MRTX_C_AOS
+                { const float4 v = nt_load4(pq.c4 + e); a0[u] = v.x; a1[u] = v.y; a2[u] = v.z; }
+#else
                 a0[u] = __builtin_nontemporal_load(pq.c0 + e);
                 a1[u] = __builtin_nontemporal_load(pq.c1 + e);
                 a2[u] = __builtin_nontemporal_load(pq.c2 + e);
+#endif
                 const uint32_t x = (mt[u] & 0x7FFFu) + (pp & ((1u << pq.pw_log2) - 1u));
                 const uint32_t y = ((mt[u] >> 15) & 0x7FFFu) + (pp >> pq.pw_log2);
                 if (ss == 0u && x < (uint32_t)f.W && y < (uint32_t)f.H) {
