@@ -17,7 +17,8 @@ scene.path_seg_min, scene.path_seg_max = (int(t) for t in os.environ.get("PATH_S
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     ms, nbytes, split = [], 0, []
     for r in range(world):
-        rt = MoonRT(W, H, device=0, rank=r, world=world)
+        tile = tuple(int(t) for t in os.environ.get("TILE", "32,32").split(","))
+        rt = MoonRT(W, H, device=0, rank=r, world=world, tile=tile)
         rt.bind_dem(dem_buf, dem_h, dem_w)
         rt.bind_color(col, col_shape[0], col_shape[1])
         rt.apply_scene(scene)
