@@ -1395,6 +1395,9 @@ __device__ __forceinline__ float tree_sum(float v) {
 #ifndef MRTX_XCD_SHARE
 #define MRTX_XCD_SHARE 1   // 0 = always whole tiles per XCD (A/B switch, see the remap in render_kernel)
 #endif
+#ifndef MRTX_XCD_TILE_RUN
+#define MRTX_XCD_TILE_RUN 1
+#endif
 #ifndef MRTX_XCD_SHARE_BELOW
 #define MRTX_XCD_SHARE_BELOW 1200   // tiles per launch under which the XCDs share every tile
 #endif
@@ -1446,7 +1449,10 @@ render_kernel(const FrameC f, const PathQ pq) {
         const int per = subs >> 3;
         li = g / per; sub = xcd * per + g % per;
     } else {
-        li = (g / subs) * 8 + xcd; sub = g % subs;
+        // an XCD takes MRTX_XCD_TILE_RUN consecutive tiles of the list at a time (raster neighbours: one L2 working set)
+        constexpr int K = MRTX_XCD_TILE_RUN;
+        const int rem = g % (subs * K);
+        li = ((g / (subs * K)) * 8 + xcd) * K + rem / subs; sub = rem % subs;
     }
     if (li >= f.n_active) return;
     const int lt = f.tile_list ? f.tile_list[li] : li;
@@ -2434,7 +2440,7 @@ static void render_geometry(const FrameC& f, int S, int& xcd_share, unsigned& gr
     const int wgt = (wgmin > wgtile) ? wgmin : wgtile;
     const int subs = (f.tile_w / wgt) * (f.tile_h / wgt);
     xcd_share = (MRTX_XCD_SHARE && (subs & 7) == 0 && f.n_active < MRTX_XCD_SHARE_BELOW) ? 1 : 0;   // see the remap in render_kernel
-    const int groups = xcd_share ? f.n_active : (f.n_active + 7) / 8 * 8;
+    const int groups = xcd_share ? f.n_active : (f.n_active + 8 * MRTX_XCD_TILE_RUN - 1) / (8 * MRTX_XCD_TILE_RUN) * (8 * MRTX_XCD_TILE_RUN);
     grid = (unsigned)(groups * subs);
     njobs = (wgt / PW) * (wgt / PH);
     pw_log2 = PW == 8 ? 3 : PW == 4 ? 2 : PW == 2 ? 1 : 0;
