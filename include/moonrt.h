@@ -44,7 +44,7 @@ typedef struct MrtxConfig {
     int32_t device;          /* HIP device ordinal                                             */
     int32_t width, height;   /* TkOptiX(width=, height=)            moon_renderer.py:571-573   */
     int32_t rank, world;     /* image-tile sharding (new; the reference is single-GPU)        */
-    int32_t tile_w, tile_h;  /* sharding / culling tile (multiples of 16), 0 = default: 16 x 16 for world 1, 32 x 32 else */
+    int32_t tile_w, tile_h;  /* sharding / culling tile (multiples of 16), 0 = default: 16 x 16 for world <= 2, 32 x 32 else */
 } MrtxConfig;
 
 /* String-keyed knobs of the reference collapsed into one POD.

@@ -460,8 +460,9 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
     c->cfg = *cfg;
     // default tile: 16 x 16 on one GPU -- the sky cull and the limb-first launch order work at tile granularity, and the finer
     // tile keeps ~2 % of cfg3's waves (all-sky pixel blocks along the limb) off the GPU: 23.7 ms against 24.2 with 32 x 32 (direct
-    // frame 12.7 / 13.2; gpurun_out/r3m/tile1.log); 32 x 32 when the frame is sharded (world 8: slowest rank 3.51 ms against 3.76)
-    const int dflt = c->cfg.world > 1 ? 32 : 16;
+    // frame 12.7 / 13.2; gpurun_out/r3m/tile1.log), and for two ranks (slowest rank 12.28 / 12.49 ms); 32 x 32 from four ranks up
+    // (world 4: 6.41 against 6.60 ms, world 8: 3.51 against 3.76: a rank's lattice of small tiles loses L2 locality)
+    const int dflt = c->cfg.world > 2 ? 32 : 16;
     if (c->cfg.tile_w <= 0) c->cfg.tile_w = dflt;
     if (c->cfg.tile_h <= 0) c->cfg.tile_h = dflt;
     if ((c->cfg.tile_w & 15) || (c->cfg.tile_h & 15)) { delete c; return MRTX_E_INVALID; }

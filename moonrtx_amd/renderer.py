@@ -60,7 +60,7 @@ class DeviceBuffer:
 
 class MoonRT:
     def __init__(self, width, height, device=0, rank=0, world=1, tile=(0, 0)):
-        """`tile` = (0, 0): the library's default sharding / culling tile (16 x 16 on one GPU, 32 x 32 when sharded)."""
+        """`tile` = (0, 0): the library's default sharding / culling tile (16 x 16 on one or two GPUs, 32 x 32 from four ranks up)."""
         self._lib = _lib.load()
         self.width, self.height = int(width), int(height)
         self.rank, self.world = int(rank), int(world)
