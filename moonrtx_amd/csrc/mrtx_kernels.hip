@@ -1616,6 +1616,7 @@ render_kernel(const FrameC f, const PathQ pq) {
 #endif
 #ifdef MRTX_PATH_PROF   // measurement build only (tools/path_prof.py): block executions and lane counts of path_kernel
 __device__ unsigned long long g_pprof[16];
+__device__ unsigned long long g_pprof_end[8192];   // end time of every persistent wave (tools/path_prof.py: the shape of the tail)
 __device__ unsigned long long g_pprof_t[16];   // [0..7] latest wave end per label, [8] earliest wave start (wall_clock64 ticks, 100 MHz), [9] waves
 #endif
 enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_BISECT, PS_ENDED, PS_HITWAIT, PS_SHADE, PS_ESCAPED };
@@ -1699,10 +1700,14 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         const int n_rare = __popcll(__ballot(state == PS_HITWAIT || state == PS_SHADE || state == PS_ESCAPED));
         // stepping is cheap and runs whenever a lane can step; the others wait for their thresholds, or until nothing cheaper
         // can make progress.  (Running only the block most lanes wait for was measured: more iterations, 18.9 ms against 17.7.)
+        // (Dropping the thresholds once the queue is empty -- no new ray will fill a block any more -- was measured: the waves of a
+        // launch still end spread over ~1.2 ms, on average 0.6 ms before the last one (tools/path_prof.py): that spread is the
+        // length of the longest of a wave's last 64 paths, 40-200 iterations of ~5 us, not time spent waiting for a threshold.)
         const bool do_step = n_step > 0;
-        const bool do_seg = n_seg > 0 && (n_seg >= pq.seg_min || n_step == 0);
+        const int seg_min = pq.seg_min, rare_min = pq.rare_min;
+        const bool do_seg = n_seg > 0 && (n_seg >= seg_min || n_step == 0);
         const bool do_refill = can_refill && nidle > 0 && (nidle >= pq.refill_min || (n_step == 0 && !do_seg));
-        const bool do_rare = n_rare > 0 && (n_rare >= pq.rare_min || (n_step == 0 && !do_seg && !do_refill));
+        const bool do_rare = n_rare > 0 && (n_rare >= rare_min || (n_step == 0 && !do_seg && !do_refill));
 #ifdef MRTX_PATH_PROF
         pf[0]++;
         if (do_refill) { pf[1]++; pf[2] += (uint32_t)nidle; }
@@ -1984,6 +1989,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
 #pragma unroll
         for (int i = 0; i < 16; i++) atomicAdd(&g_pprof[i], (unsigned long long)pf[i]);
         atomicMax(&g_pprof_t[label], (unsigned long long)wall_clock64());
+        if (blockIdx.x < 8192u) g_pprof_end[blockIdx.x] = (unsigned long long)wall_clock64();
     }
 #endif
     if (STATS) {
@@ -2560,6 +2566,9 @@ extern "C" __attribute__((visibility("default"))) int mrtx_pprof_read(unsigned l
         if (hipMemcpyToSymbol(HIP_SYMBOL(mrtx::g_pprof), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
+}
+extern "C" __attribute__((visibility("default"))) int mrtx_pprof_ends(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mrtx::g_pprof_end), (size_t)(n < 8192 ? n : 8192) * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 extern "C" __attribute__((visibility("default"))) int mrtx_pprof_times(unsigned long long* out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mrtx::g_pprof_t), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;

@@ -20,7 +20,7 @@ tms = (C.c_ulonglong * 16)()
 settings = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(32, 16, 16)]
 for (refill, segmin, rare) in settings:
     os.environ.update(MOONRT_PATH_REFILL=str(refill), MOONRT_PATH_SEGMIN=str(segmin), MOONRT_PATH_HITMIN=str(rare))
-    rt = MoonRT(W, H); rt.bind_dem(dem, dem_h, dem_w); rt.bind_color(col, *col_shape); rt.apply_scene(scene); rt.set_params(flags=int(os.environ.get("FLAGS", "0")))
+    rt = MoonRT(W, H, rank=int(os.environ.get("RANK_", "0")), world=int(os.environ.get("WORLD_", "1"))); rt.bind_dem(dem, dem_h, dem_w); rt.bind_color(col, *col_shape); rt.apply_scene(scene); rt.set_params(flags=int(os.environ.get("FLAGS", "0")))
     if os.environ.get("STARMAP"):     # the reference's environment (moon_renderer.py:604-607); STARMAP=black: an all-zero one
         import bench
         sm = bench.synth_starmap(8192, 16384)
@@ -35,6 +35,14 @@ for (refill, segmin, rare) in settings:
         print(f"    {n:7s} executions {ex:12d} ({ex / max(1, v[0]):.2f} per iteration)  lanes waiting {ln / max(1, ex):5.1f}")
     t = list(tms)
     print("    last wave of each label ends after " + ", ".join(f"{(t[i] - t[8]) / 100.0:.0f}" for i in range(8)) + " us (first wave start = 0)")
+    if hasattr(lib, "mrtx_pprof_ends"):
+        import numpy as np
+        ends = (C.c_ulonglong * 5120)()
+        lib.mrtx_pprof_ends.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        lib.mrtx_pprof_ends(ends, 5120)
+        e = (np.array(list(ends), np.float64) - t[8]) / 100.0
+        e = np.sort(e[e > 0])
+        print("    wave end times (us after the first wave's start): " + ", ".join(f"p{q}: {np.percentile(e, q):.0f}" for q in (1, 10, 50, 90, 99)) + f", last {e[-1]:.0f}; mean idle at the end {e[-1] - e.mean():.0f} us")
     tot = sum(v[9:14])
     if tot:
         names = ("bookkeeping + refill", "set-up", "step", "segment end + march over", "rare")
