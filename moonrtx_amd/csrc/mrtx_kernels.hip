@@ -1614,6 +1614,11 @@ render_kernel(const FrameC f, const PathQ pq) {
 #ifndef MRTX_PATH_STEPS
 #define MRTX_PATH_STEPS 2
 #endif
+#ifndef MRTX_PATH_WIDE
+#define MRTX_PATH_WIDE 0      // 1 = wide stepping while a wave drains (see the kernel body): bit-exact, measured SLOWER (path stage 5.44 ms
+                              // against 5.13 on one GPU, 0.98 / 0.91 ms for a rank of eight): the block costs three more spilled registers
+                              // in the main phase, more than the shorter drain gives back -- an A/B switch, off
+#endif
 #ifdef MRTX_PATH_PROF   // measurement build only (tools/path_prof.py): block executions and lane counts of path_kernel
 __device__ unsigned long long g_pprof[16];
 __device__ unsigned long long g_pprof_end[8192];   // end time of every persistent wave (tools/path_prof.py: the shape of the tail)
@@ -1822,12 +1827,77 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             }
         }
         PPROF_T(10);
+#if MRTX_PATH_WIDE
+        // ---- DRAIN, wide stepping: once the queue is empty a wave ends when its last path does, and a marching path needs an
+        // iteration per MRTX_PATH_STEPS steps while most lanes idle.  With at most four lanes stepping, each of them borrows a
+        // quarter of the wave: lane 16 g + i evaluates step j + i of the g-th stepping lane's segment, and the owner takes the
+        // first step (in march order) that ends the march -- the same evaluations in the same order as one step at a time, a
+        // whole segment per iteration.  Results and counters unchanged (the steps behind the terminating one are not counted).
+        bool wide_done = false;
+        {
+            const uint64_t stepm = __ballot(state == PS_STEP);
+            const int nst = __popcll(stepm);
+            if (!more && nst > 0 && nst <= 4) {            // wave-uniform
+                const uint32_t grp = lane >> 4, sub16 = lane & 15u;
+                int src = -1;
+                {
+                    uint64_t mm = stepm;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) {
+                        const int bpos = mm ? (int)__builtin_ctzll(mm) : -1;
+                        src = (i == grp) ? bpos : src;
+                        mm &= mm - 1ull;
+                    }
+                }
+                const bool has = src >= 0;
+                const int sl = has ? src : 0;
+                Seg wsg;
+                const float woa = __shfl(m.oa, sl, 64), wob = __shfl(m.ob, sl, 64), woc = __shfl(m.oc, sl, 64);
+                const float wda = __shfl(m.da, sl, 64), wdb = __shfl(m.db, sl, 64), wdc = __shfl(m.dc, sl, 64);
+                wsg.sa = __shfl(sg.sa, sl, 64); wsg.ra = __shfl(sg.ra, sl, 64); wsg.r1 = __shfl(sg.r1, sl, 64); wsg.r2 = __shfl(sg.r2, sl, 64);
+                wsg.ca = __shfl(sg.ca, sl, 64); wsg.c1 = __shfl(sg.c1, sl, 64); wsg.c2 = __shfl(sg.c2, sl, 64);
+                wsg.exact = __shfl((int)sg.exact, sl, 64) != 0;
+                wsg.jlo = 1; wsg.jhi = SEG_N;
+                const int wka = __shfl(m.ka, sl, 64), wj = __shfl(j, sl, 64), wjhi = __shfl(sg.jhi, sl, 64);
+                const int jj = wj + (int)sub16;
+                const bool valid = has && jj <= wjhi;
+                const int kk = wka + min(jj, wjhi);
+                const float wsk = (float)kk * f.step;
+                const float wpa = fmaf(wsk, wda, woa), wpb = fmaf(wsk, wdb, wob), wpc = fmaf(wsk, wdc, woc);
+                const float wr2 = fmaf(wpc, wpc, fmaf(wpb, wpb, wpa * wpa));
+                const bool win = (wr2 <= f.R2f) & (kk <= f.kmax);
+                const bool wbel = below_seg<WIDE, true, MRTX_PATH_CP>(f, wsg, wsk, wpa, wpb, wpc, wr2);
+                const uint64_t hm = __ballot(valid & win & wbel), om = __ballot(valid & !win);
+                if (state == PS_STEP) {
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(stepm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)stepm, 0u));   // < 4
+                    const uint32_t h16 = (uint32_t)(hm >> (16u * rk)) & 0xFFFFu, o16 = (uint32_t)(om >> (16u * rk)) & 0xFFFFu;
+                    const int nvalid = min(16, sg.jhi - j + 1);
+                    const uint32_t term = h16 | o16;
+                    if (term != 0u) {
+                        const int t = (int)__builtin_ctz(term);
+                        const bool is_hit = ((h16 >> t) & 1u) != 0u;
+                        if (STATS) { cnt[ST_HEIGHT] += (uint32_t)t + (is_hit ? 1u : 0u); cnt[ST_FETCH] += (uint32_t)t + 1u; }
+                        if (is_hit) { hit = true; sk_hit = (float)(m.ka + j + t) * f.step; }
+                        j += t + 1;
+                        state = PS_ENDED;
+                    } else {
+                        if (STATS) { cnt[ST_HEIGHT] += (uint32_t)nvalid; cnt[ST_FETCH] += (uint32_t)nvalid; }
+                        j += nvalid;
+                        if (j > sg.jhi) segend = true;
+                    }
+                }
+                wide_done = true;
+            }
+        }
+#else
+        const bool wide_done = false;
+#endif
         if (do_step) {
             // ---- the next MRTX_PATH_STEPS steps of every stepping lane: their DEM footprints are fetched together (one
             // memory round trip per iteration is what bounds this kernel), then the steps are tested in march order and
             // whatever follows the one that ends the march or the segment is dropped (its fetch is wasted).  Same
             // evaluations, same order, same results as one step at a time.  cfg3: 1 step 14.5 ms, 2 steps 13.3.
-            if (state == PS_STEP || state == PS_BISECT) {
+            if ((state == PS_STEP && !wide_done) || state == PS_BISECT) {
                 // A BISECT lane evaluates the mid-point of its bracket in slot 0 and, speculatively, the mid-point of the
                 // lower half in slot 1 (the next level if slot 0 turns out below the surface): the bisection of D3 rides the
                 // fetch rounds of the march instead of adding five of its own to the rare block.
