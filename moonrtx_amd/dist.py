@@ -68,6 +68,18 @@ def init_process_group(backend=None):
     return rank, world, local
 
 
+def gather_parts(world, shard_bytes, requested=0):
+    """In how many parts a rank renders + gathers its tile list.  `requested` > 0 (MOONRT_GATHER_PARTS) wins; else two parts from
+    32 MB per rank up, one below: a part costs a render + path-stage + resolve launch of its own (+0.3 ms per rank at cfg3, measured
+    rank after rank on one GPU: profiles/r03_rank_balance.md) and hides the transfer of the OTHER part only (~50 GB/s per xGMI link
+    assumed, unmeasured here) -- at cfg3 that pays for two ranks (50 MB each), not for four (25 MB) or eight (12.6 MB)."""
+    if world <= 1:
+        return 1
+    if requested > 0:
+        return int(requested)
+    return 2 if shard_bytes >= (32 << 20) else 1
+
+
 class FrameGather:
     """Reusable buffers + the gather of packed shards to rank 0.
 
@@ -103,11 +115,7 @@ class FrameGather:
         if parts is None:
             parts = int(os.environ.get("MOONRT_GATHER_PARTS", "0"))
         if parts <= 0:
-            # A part costs a render + path-stage + resolve launch of its own: +0.3 ms per rank at cfg3 (one GPU, rank after rank:
-            # world 8 4.03 ms in two parts against 3.58 in one, world 2 12.96 / 12.73; profiles/r03_rank_balance.md), and hides the
-            # exchange of the OTHER part.  That pays only while half a shard takes longer than that over one xGMI link
-            # (~50 GB/s assumed, unmeasured here): two parts from 32 MB per rank up (cfg3: world 2), one below (world 4, 8).
-            parts = 2 if (self.world > 1 and hasattr(r, "shard_bytes_active") and r.shard_bytes_active() >= (32 << 20)) else 1
+            parts = gather_parts(self.world, r.shard_bytes_active() if hasattr(r, "shard_bytes_active") else 0)
         P = r.shard_parts(parts) if (self.world > 1 and parts > 1 and hasattr(r, "shard_parts") and not self.host_staged) else 1
         if P == 1:
             st = r.render(n_blocks)

@@ -113,3 +113,12 @@ def test_tile_ownership_is_a_partition():
         # interleave => balanced: every rank within one tile of the others
         counts = [len(mdist.tiles_of(r, world, 3840, 2160)[0]) for r in range(world)]
         assert max(counts) - min(counts) <= 1
+
+
+def test_gather_parts_follow_the_shard_size():
+    """One part below 32 MB per rank, two from there up (cfg3: 50.1 / 25.1 / 12.6 MB at world 2 / 4 / 8); an explicit request wins."""
+    from moonrtx_amd.dist import gather_parts
+    assert gather_parts(1, 500 << 20) == 1
+    assert gather_parts(2, 50069504) == 2 and gather_parts(4, 25100000) == 1 and gather_parts(8, 12600000) == 1
+    assert gather_parts(8, 12600000, requested=2) == 2 and gather_parts(2, 50069504, requested=1) == 1
+    assert gather_parts(8, 32 << 20) == 2 and gather_parts(8, (32 << 20) - 1) == 1
