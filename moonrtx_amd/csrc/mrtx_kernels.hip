@@ -1404,10 +1404,13 @@ __device__ __forceinline__ float tree_sum(float v) {
 #ifndef MRTX_MIN_WAVES_BOUNCE
 #define MRTX_MIN_WAVES_BOUNCE 5   // 8 spilled VGPRs at 5 waves/SIMD still beat 4 waves without spills (36.1 vs 39.8 ms)
 #endif
-// The COUNTING bounce variants carry the counter array on top of the path state and want ~180 VGPRs: under the 96-VGPR
-// cap they spill ~200 registers, and in an experiment at a 72-VGPR cap one such instantiation (<64, STATS, !WIDE, BOUNCE,
-// OVERLAY>) miscomputed a sample with no undefined behaviour the compiler could name.  They only render the counted
-// frame, so they get the registers they ask for.
+// The COUNTING in-wave variants carry the counter array on top of the path state and want ~180-200 VGPRs; they only render
+// the counted frame, so they get the registers they ask for (2 waves per SIMD, no VGPR spills) -- a performance choice.
+// What is known about the round-1 report that one of them (<64, STATS, !WIDE, in-wave, OVERLAY>) miscomputed a sample when
+// held to 72 VGPRs (~270 spilled): the failing case was not kept; the configuration has been rebuilt since (make spilltest)
+// and 540 fuzz scenes through exactly that kernel equal the oracle in radiance, hits and counters; the march state was
+// restructured in round 2 (every field initialised before use); the oracle is clean under ASan / UBSan.  No miscompute has
+// been observed since, and tests/test_gpu_fuzz.py re-runs the spilled build every round.
 #ifndef MRTX_BOUNCE_STATS_WAVES
 #define MRTX_BOUNCE_STATS_WAVES 2   // tools/spill_repro.py builds with 7 to bring the spilled configuration back
 #endif
