@@ -119,9 +119,10 @@ struct mrtx_ctx {
 };
 
 // Host -> device copies that feed kernels of this context go through the context's OWN stream (hipStreamNonBlocking: the null
-// stream does not order it) and are waited for before the host buffer is released: copy and consumer are ordered by the stream,
-// whatever path the runtime takes for small pageable copies (round 3: a non-repeating one-off mismatch in 7 000 fuzz cases had a
-// 912-byte colour map uploaded by a null-stream hipMemcpy right before color_pair_kernel on this stream; cause never established).
+// stream does not order it) and are waited for before the host buffer is released, so copy and consumer are ordered by the
+// stream itself.  (Introduced in round 3 on suspicion while a one-off fuzz mismatch was open; round 4 showed that mismatch to
+// be a changed INPUT -- one word of the caller's colour-map array decremented by one before the upload,
+// profiles/r04_seed601_case49.md -- so this is plain hygiene, not a fix of anything observed.)
 static hipError_t h2d(mrtx_ctx* c, void* dst, const void* src, size_t bytes) {
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
