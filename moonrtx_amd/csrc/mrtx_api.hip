@@ -936,15 +936,22 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     double primary_ms = 0.0, paths_ms = 0.0;
     uint32_t launches = 0;
     if (mode != 2) {
+        // one launch per block of S samples (round 4: a kernel that knows it traces ONE block keeps nothing alive from block to
+        // block -- 25 to 48 VGPRs less, see render_kernel; a launch costs ~10 us, a block of a 4K frame milliseconds)
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-        if (f.n_active > 0 || !f.tile_list) HIPCHK(c, mrtx_launch_render(f, S, stats, mode, overlay, nullptr, c->stream));
-        if (have_sky) HIPCHK(c, mrtx_launch_render(fsky, S, stats, 3, false, nullptr, c->stream));
+        for (int32_t b = 0; b < n_blocks; b++) {
+            FrameC fb = f, fsb = fsky;
+            fb.first_block = fsb.first_block = c->blocks_done + (uint32_t)b;
+            fb.n_blocks = fsb.n_blocks = 1;
+            if (f.n_active > 0 || !f.tile_list) HIPCHK(c, mrtx_launch_render(fb, S, stats, mode, overlay, nullptr, c->stream));
+            if (have_sky) HIPCHK(c, mrtx_launch_render(fsb, S, stats, 3, false, nullptr, c->stream));
+        }
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         primary_ms = ms;
-        launches = ((f.n_active > 0 || !f.tile_list) ? 1u : 0u) + (have_sky ? 1u : 0u);
+        launches = (((f.n_active > 0 || !f.tile_list) ? 1u : 0u) + (have_sky ? 1u : 0u)) * (uint32_t)n_blocks;
     } else {
         const int wi = (stats ? 2 : 0) + (f.dem_wide ? 1 : 0);
         if (c->path_waves[wi] == 0) {
@@ -975,7 +982,11 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         }
         if (have_sky) {   // nothing but the environment can be seen from these tiles: no paths, no records
             HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-            HIPCHK(c, mrtx_launch_render(fsky, S, stats, 3, false, nullptr, c->stream));
+            for (int32_t b = 0; b < n_blocks; b++) {
+                FrameC fsb = fsky;
+                fsb.first_block = c->blocks_done + (uint32_t)b; fsb.n_blocks = 1;
+                HIPCHK(c, mrtx_launch_render(fsb, S, stats, 3, false, nullptr, c->stream));
+            }
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         }
         // path_kernel's watchdog (stats[15]): a wave gave up after 2^24 iterations -- the frame is incomplete.  Read through
@@ -1001,7 +1012,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             HIPCHK(c, hipEventElapsedTime(&p, c->evs[i * 3 + 1], c->evs[i * 3 + 2]));
             primary_ms += a; paths_ms += p;
         }
-        launches = (f.n_active > 0 ? 3u * (uint32_t)n_blocks * (uint32_t)n_sub : 0u) + (have_sky ? 1u : 0u);
+        launches = (f.n_active > 0 ? 3u * (uint32_t)n_blocks * (uint32_t)n_sub : 0u) + (have_sky ? (uint32_t)n_blocks : 0u);
     }
     if (part == n_parts - 1) c->blocks_done += (uint32_t)n_blocks;
     if (out) {

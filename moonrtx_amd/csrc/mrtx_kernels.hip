@@ -1059,6 +1059,29 @@ __device__ __forceinline__ bool sky_pixel_uniform(const FrameC& f, int x, int y,
     return uni;
 }
 
+// ---- LDS as the spill space of render_kernel<MODE 2> (round 4, MRTX_LDS_PARK).
+// The kernel's time follows the waves a SIMD holds (1 -> 2 -> 3 -> 4 waves: 52 -> 29 -> 23 -> 19 ms, profiles/r03_mode2_ab.md) and the
+// fifth wave needs <= 96 VGPRs; the compiler's own 96-VGPR code spills 17 registers to scratch and loses its load clustering.  What
+// is COLD while a march runs -- the first vertex (point, normal, albedo: 9), the sample's RNG key and the radiance the light sample
+// carries across the shadow march; the running radiance, throughput and key across the trial segment -- is parked in LDS instead:
+// lane-private 16-byte slots (ds_write_b128 / ds_read_b128, consecutive lanes = consecutive 16-byte slots: conflict-free), three
+// slots = 3 KB per wave, 60 KB per CU at 20 waves.  The values come back bit for bit, so nothing in the arithmetic changes.
+// A compiler-level memory barrier on either side keeps LLVM from forwarding the stored values to the loads (which would keep them
+// in registers after all).
+#ifndef MRTX_LDS_PARK
+#define MRTX_LDS_PARK 1
+#endif
+#define MRTX_PARK_SLOTS 3
+#ifndef MRTX_WG_WAVES
+#define MRTX_WG_WAVES 1       // waves per workgroup of render_kernel (see there)
+#endif
+__device__ __forceinline__ void park_put(v4f* park, int slot, float a, float b, float c, float d) {
+    const v4f v = {a, b, c, d};
+    park[slot * (64 * MRTX_WG_WAVES) + threadIdx.x] = v;
+}
+__device__ __forceinline__ v4f park_get(const v4f* park, int slot) { return park[slot * (64 * MRTX_WG_WAVES) + threadIdx.x]; }
+__device__ __forceinline__ void park_fence() { asm volatile("" ::: "memory"); }
+
 struct SampleOut {
     float c0, c1, c2, hitflag;
     float h0, h1, h2, h3;
@@ -1074,11 +1097,20 @@ struct SampleOut {
 // sphere, the Sun disk or an overlay tube (cull_tiles), so a sample is its environment texel and nothing else
 template <bool STATS, bool WIDE, int MODE, bool OVERLAY>
 __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int y, uint32_t gs, SampleOut& o,
-                                             uint32_t* cnt) {
-    // (writing the hit record from here, as soon as it is known, instead of carrying it to the end of the wave was measured:
-    // 13.33 ms against 13.21 for the direct frame, no difference with paths -- the single late store stays)
-    auto emit_hit = [&](float h0, float h1, float h2, float h3) { o.h0 = h0; o.h1 = h1; o.h2 = h2; o.h3 = h3; };
+                                             uint32_t* cnt, bool lead = false, v4f* park = nullptr) {
     constexpr bool BOUNCE = MODE == 1, DEFER = MODE == 2;
+    constexpr bool PARK = DEFER && MRTX_LDS_PARK != 0;
+    // (writing the hit record from here, as soon as it is known, instead of carrying it to the end of the wave was measured for the
+    // direct kernel: 13.33 ms against 13.21 -- its single late store stays.  render_kernel<MODE 2> with MRTX_LDS_PARK is held to 96
+    // VGPRs, where four registers carried through three marches do count: its launches hold ONE block, so the record of sample 0
+    // (`lead`) IS the frame's hit record and goes to memory right here)
+    auto emit_hit = [&](float h0, float h1, float h2, float h3) {
+        if (PARK) {
+            if (lead) reinterpret_cast<float4*>(CF(f)->hits)[(int64_t)y * f.W + x] = make_float4(h0, h1, h2, h3);
+        } else {
+            o.h0 = h0; o.h1 = h1; o.h2 = h2; o.h3 = h3;
+        }
+    };
     constexpr int BATCH = BOUNCE ? MRTX_STEP_BATCH_BOUNCE : MRTX_STEP_BATCH;   // incoherent bounce rays waste the speculative fetches
     const uint32_t pix = (uint32_t)y * (uint32_t)f.W + (uint32_t)x;
     const uint32_t kp = mix32(pix + CF(f)->key0);
@@ -1087,6 +1119,10 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     o.c0 = o.c1 = o.c2 = 0.0f; o.hitflag = 0.0f;
     o.h0 = o.h1 = o.h2 = o.h3 = 0.0f;
     o.path = false;
+    // the hand-over fields mean something only while o.path is set: (re)initialised HERE, per sample, they are constants until
+    // a path assigns them -- initialised once outside the caller's block loop they were loop-carried values, thirteen registers
+    // held through every march of the sample for nothing
+    if (DEFER) { o.oa = o.ob = o.oc = o.da = o.db = o.dc = o.t0 = o.t1 = o.t2 = o.row = o.col = 0.0f; o.ks = 0u; o.aux = 0u; }
     if (STATS) cnt[ST_PRIMARY]++;
     PROF_BEGIN(1);
 
@@ -1282,9 +1318,34 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         return;
     }
 #endif
+    uint32_t ksl = ks;      // the sample's RNG key as the continuation uses it (PARK: the copy that came back from LDS)
     for (;;) {
         PROF_BEGIN(5);
-        const float wgt = direct_light<STATS, WIDE, BATCH>(f, v, ul1, ul2, cnt);
+        float wgt;
+        if (PARK) {
+            // direct_light() with the vertex, the key and the carried radiance parked in LDS while the shadow ray marches
+            float oa, ob, oc, wa, wb, wc, carried = 0.0f;
+            const bool have_s = light_sample(f, v, ul1, ul2, oa, ob, oc, wa, wb, wc, carried);
+            park_put(park, 0, v.pa, v.pb, v.pc, v.na);
+            park_put(park, 1, v.nb, v.nc, v.al0, v.al1);
+            park_put(park, 2, v.al2, __uint_as_float(ksl), carried, 0.0f);
+            park_fence();
+            bool occluded = false;
+            if (have_s) {
+                if (STATS) cnt[ST_SHADOW]++;
+                Seg ssg;
+                float sk_occ;
+                occluded = march<WIDE, false, STATS, BATCH>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt);
+            }
+            park_fence();
+            const v4f p0 = park_get(park, 0), p1 = park_get(park, 1), p2 = park_get(park, 2);
+            v.pa = p0.x; v.pb = p0.y; v.pc = p0.z; v.na = p0.w;
+            v.nb = p1.x; v.nc = p1.y; v.al0 = p1.z; v.al1 = p1.w;
+            v.al2 = p2.x; ksl = __float_as_uint(p2.y);
+            wgt = (have_s && !occluded) ? p2.z : 0.0f;
+        } else {
+            wgt = direct_light<STATS, WIDE, BATCH>(f, v, ul1, ul2, cnt);
+        }
         PROF_END(5);
         o.c0 = fmaf(t0r * v.al0, wgt, o.c0);
         o.c1 = fmaf(t1r * v.al1, wgt, o.c1);
@@ -1293,11 +1354,11 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
             // The path goes on in path_kernel.  What is still coherent -- the 64 samples of a pixel decide together
             // whether to continue, build their continuation rays and locate the ray origins on the DEM grid -- is done
             // here at full occupancy; the queue record is a ray that is ready to march.
-            if (continue_path(f, v, ks, 1u, t0r, t1r, t2r, o.oa, o.ob, o.oc, o.da, o.db, o.dc)) {
+            if (continue_path(f, v, ksl, 1u, t0r, t1r, t2r, o.oa, o.ob, o.oc, o.da, o.db, o.dc)) {
                 float q2;
                 exact_rowcol(f, o.oa, o.ob, o.oc, o.row, o.col, q2);
                 o.t0 = t0r; o.t1 = t1r; o.t2 = t2r;
-                o.ks = ks; o.aux = 0u;
+                o.ks = ksl; o.aux = 0u;
                 if (STATS) cnt[ST_BOUNCE]++;
 #if MRTX_TRIAL_SEGMENT
                 // The FIRST segment of the continuation ray is marched right here: the 64 rays of the pixel still start
@@ -1319,10 +1380,22 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 }
                 MarchState tm;
                 tm.rowA = o.row; tm.colA = o.col;
+                if (PARK) {     // the radiance so far, the throughput and the key sit out the trial segment in LDS
+                    park_put(park, 0, o.c0, o.c1, o.c2, o.t0);
+                    park_put(park, 1, o.t1, o.t2, __uint_as_float(o.ks), 0.0f);
+                    park_fence();
+                }
                 bool tgo = march_begin_at<false, STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, tm, tcnt), thit = false;
                 Seg tsg;
                 float tsk = 0.0f;
                 if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH, MRTX_TRIAL_CP>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
+                if (PARK) {
+                    park_fence();
+                    const v4f p0 = park_get(park, 0), p1 = park_get(park, 1);
+                    o.c0 = p0.x; o.c1 = p0.y; o.c2 = p0.z; o.t0 = p0.w;
+                    o.t1 = p1.x; o.t2 = p1.y; o.ks = __float_as_uint(p1.z);
+                    t0r = o.t0; t1r = o.t1; t2r = o.t2;
+                }
 #ifdef MRTX_PROF_TRIAL   // measurement only: the trial's step iterations and the lanes evaluating in them (slots 13 / 14), its cycles (15)
                 cnt[13] += tcnt[11]; cnt[14] += tcnt[12]; cnt[15] += tcnt[6] + tcnt[7];
 #endif
@@ -1435,6 +1508,9 @@ render_kernel(const FrameC f, const PathQ pq) {
     constexpr int WGS = WGT == 16 ? 4 : WGT == 8 ? 3 : WGT == 4 ? 2 : WGT == 2 ? 1 : 0;
     constexpr int JX = WGT / PW, JY = WGT / PH, NJOBS = JX * JY;
     __shared__ unsigned int lds_cnt[ST_N];
+    constexpr bool PARK = DEFER && MRTX_LDS_PARK != 0;
+    __shared__ v4f park_lds[PARK ? MRTX_PARK_SLOTS * 64 * MRTX_WG_WAVES : 1];
+    v4f* const park = PARK ? park_lds : nullptr;
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD-aware remap: consecutive blockIdx values go to XCDs round-robin, so block b and b+8 share an XCD (and its
@@ -1508,10 +1584,10 @@ render_kernel(const FrameC f, const PathQ pq) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f.first_block != 0) a = reinterpret_cast<const float4*>(CF(f)->accum)[upix];
             const float b0 = (float)S * sky0, b1 = (float)S * sky1, b2 = (float)S * sky2;
-            for (uint32_t blk = 0; blk < f.n_blocks; blk++) { a.x += b0; a.y += b1; a.z += b2; a.w += 0.0f; }
+            a.x += b0; a.y += b1; a.z += b2; a.w += 0.0f;     // one block per launch
             reinterpret_cast<float4*>(CF(f)->accum)[upix] = a;
             reinterpret_cast<float4*>(CF(f)->hits)[upix] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (STATS) { cnt[ST_PRIMARY] += (uint32_t)S * f.n_blocks; cnt[ST_BG] += (uint32_t)S * f.n_blocks; }
+            if (STATS) { cnt[ST_PRIMARY] += (uint32_t)S; cnt[ST_BG] += (uint32_t)S; }
         }
     }
     for (int job = wv; job < NJOBS; job += MRTX_WG_WAVES) {
@@ -1526,10 +1602,15 @@ render_kernel(const FrameC f, const PathQ pq) {
         o.path = false;
         o.oa = o.ob = o.oc = o.da = o.db = o.dc = o.t0 = o.t1 = o.t2 = o.row = o.col = 0.f; o.ks = 0u; o.aux = 0u;
         bool deferred = false;
-        for (uint32_t blk = 0; blk < f.n_blocks; blk++) {   // DEFER launches carry one block each
+        // A launch carries ONE block of S samples per pixel (mrtx_launch_render checks it; mrtx_render_part launches block after
+        // block).  Round 4: with the block count a run-time value the compiler kept everything a sample can hand to the next
+        // iteration -- running sums, hit record, hand-over fields, hoisted per-pixel invariants -- alive through every march:
+        // render_kernel<MODE 2> 121 VGPRs (4 waves per SIMD); with a trip count of one 73 (6 waves), 62 with MRTX_LDS_PARK (8).
+        constexpr uint32_t n_blk = 1u;
+        for (uint32_t blk = 0; blk < n_blk; blk++) {
             o.c0 = o.c1 = o.c2 = o.hitflag = 0.f;
             PROF_BEGIN(0);
-            if (inb) trace_sample<STATS, WIDE, MODE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt);
+            if (inb) trace_sample<STATS, WIDE, MODE, OVERLAY>(f, lt, x, y, (f.first_block + blk) * (uint32_t)S + (uint32_t)s, o, cnt, s == 0, park);
             PROF_END(0);
             if (blk == 0 && f.first_block != 0 && inb && s == 0) {
                 // the running sums of earlier launches are fetched HERE, not before the first block was traced (four registers
@@ -1572,7 +1653,7 @@ render_kernel(const FrameC f, const PathQ pq) {
             s3 += tree_sum<S>(o.hitflag);
         }
         if (inb && s == 0) reinterpret_cast<float4*>(CF(f)->accum)[(int64_t)y * f.W + x] = make_float4(s0, s1, s2, s3);
-        if (inb && s == 0) reinterpret_cast<float4*>(CF(f)->hits)[(int64_t)y * f.W + x] = make_float4(o.h0, o.h1, o.h2, o.h3);
+        if (!PARK && inb && s == 0) reinterpret_cast<float4*>(CF(f)->hits)[(int64_t)y * f.W + x] = make_float4(o.h0, o.h1, o.h2, o.h3);   // PARK: trace_sample stored it
     }
 
 #ifdef MRTX_PROF
@@ -2506,6 +2587,17 @@ __global__ void mip_pair_kernel(const float* __restrict__ mip, float2* __restric
 
 }  // namespace mrtx
 
+#ifdef MRTX_DEV_ONE
+// resource-usage / disassembly builds (tools/one_kernel.sh): ONE instantiation, device code only, seconds instead of minutes
+#ifndef MRTX_DEV_ONE_MODE
+#define MRTX_DEV_ONE_MODE 2
+#endif
+#if MRTX_DEV_ONE_MODE == 9
+template __global__ void mrtx::path_kernel<false, true>(const FrameC, const PathQ);
+#else
+template __global__ void mrtx::render_kernel<64, false, true, MRTX_DEV_ONE_MODE, false>(const FrameC, const PathQ);
+#endif
+#else
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mrtx_api.hip)
 extern "C++" {
@@ -2539,11 +2631,12 @@ hipError_t mrtx_launch_render(const FrameC& f, int S, bool stats, int mode, bool
     int njobs, pwl; unsigned gx;
     render_geometry(f, S, fr.xcd_share, gx, njobs, pwl, mode);
     const dim3 grid(gx), block(64 * MRTX_WG_WAVES);
+    if (f.n_blocks != 1) return hipErrorInvalidValue;   // one block of S samples per launch (see render_kernel)
     if (grid.x == 0) return hipSuccess;
     PathQ q;
     memset(&q, 0, sizeof q);
     if (mode == 2) {
-        if (!pq || pq->n_chunks != (uint64_t)gx * (uint64_t)njobs || pq->grid_a != gx || (1 << pq->njobs_log2) != njobs || f.n_blocks != 1)
+        if (!pq || pq->n_chunks != (uint64_t)gx * (uint64_t)njobs || pq->grid_a != gx || (1 << pq->njobs_log2) != njobs)
             return hipErrorInvalidValue;
         q = *pq;
     }
@@ -2754,3 +2847,4 @@ hipError_t mrtx_launch_pad_dem(const float* src, float* dst, int h, int w, hipSt
     return hipGetLastError();
 }
 }
+#endif   // MRTX_DEV_ONE
