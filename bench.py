@@ -36,7 +36,8 @@ WORKLOADS = {
     "cfg4": (7680, 4320, 256, 46080, 92160, (13680, 27360)),
 }
 COUNT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "bounce_rays", "height_samples", "colour_fetches",
-              "background_fetches", "dem_fetches", "mip_fetches")
+              "background_fetches", "dem_fetches", "mip_fetches", "camera_height_samples", "camera_dem_fetches",
+              "camera_mip_fetches", "camera_colour_fetches", "camera_background_fetches")
 
 
 def synth_starmap(h, w, seed=0x53544152, n_stars=400000):
@@ -124,6 +125,65 @@ def cpu_baseline(scene, dem_buf, dem_shape, col_buf, col_shape, frame_stats, bud
     }
 
 
+def _numpy_band(job):
+    """Worker of cpu_baseline_numpy (a spawned process: numpy only, never the GPU): one row band of a crop."""
+    dem_path, scene_vars, spp, region = job
+    import types
+    import numpy as np
+    from oracle import numpy_march
+    dem = np.load(dem_path, mmap_mode="r")
+    c = {}
+    t = time.perf_counter()
+    numpy_march.render(types.SimpleNamespace(**scene_vars), dem, spp, spec_rng=True, region=region, counts=c)
+    return c["rays"], c["dem_samples"], time.perf_counter() - t
+
+
+def host_workers():
+    """Worker processes for the numpy baseline: the cores this process may use (affinity mask, cgroup quota), capped by
+    MOONRT_CPU_WORKERS (default 16 -- a one-GPU box of the pool shares its 256-core host and asks for pools of that size)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("MOONRT_CPU_WORKERS", "16"))))
+
+
+def cpu_baseline_numpy(scene, dem, workers, spp, region, tag):
+    """The baseline north_star names: a NUMPY ray-march of the same scene (oracle/numpy_march.py: library trig, float64, every
+    step evaluated exactly -- camera ray, bisection, normal, one light sample + marched shadow ray; it has no path continuation,
+    so it is timed on the direct-light model), `multiprocessing` over row bands on this host's cores."""
+    import multiprocessing as mp
+    import tempfile
+    import numpy as np
+    x0, y0, x1, y1 = region
+    bands = min(workers * 2, y1 - y0)
+    edges = [y0 + (y1 - y0) * i // bands for i in range(bands + 1)]
+    fd, path = tempfile.mkstemp(suffix=".npy", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    os.close(fd)
+    try:
+        np.save(path, dem)
+        sv = {k: v for k, v in vars(scene).items()}
+        jobs = [(path, sv, spp, (x0, edges[i], x1, edges[i + 1])) for i in range(bands) if edges[i + 1] > edges[i]]
+        with mp.get_context("spawn").Pool(workers) as pool:
+            pool.map(_numpy_band, [(path, sv, 1, (x0, y0, min(x1, x0 + 8), min(y1, y0 + 8)))] * workers)   # imports, page-in: untimed
+            t = time.perf_counter()
+            res = pool.map(_numpy_band, jobs)
+            dt = time.perf_counter() - t
+    finally:
+        os.unlink(path)
+    rays = sum(r[0] for r in res)
+    dem_samples = sum(r[1] for r in res)
+    return {"workload": tag, "rays": int(rays), "dem_samples": int(dem_samples), "seconds": round(dt, 3),
+            "mrays_per_s": round(rays / dt / 1e6, 4), "dem_samples_per_s": round(dem_samples / dt, 1), "workers": workers}
+
+
 def facade_rates(dem_buf, dem_h, dem_w, col_buf, col_shape, W, H, cycles=8):
     """Frames per second THROUGH the PlotOptiX-named surface (moonrtx_amd.tkoptix.TkOptiX.render_cycle: launch(es),
     on_launch_finished callbacks, the tone-mapped RGBA8 image in host memory) for the two cycles the reference alternates
@@ -131,8 +191,10 @@ def facade_rates(dem_buf, dem_h, dem_w, col_buf, col_shape, W, H, cycles=8):
     from moonrtx_amd.tkoptix import TkOptiX
     from moonrtx_amd.scene import named_scene
     out = {}
-    for label, frames in (("preview_1spp", 1), ("converged_64spp", 64)):
-        rt = TkOptiX(width=W, height=H, start_now=False)
+    for label, frames, progressive in (("preview_1spp", 1, False), ("converged_64spp", 64, False), ("converged_64spp_progressive", 64, True)):
+        if progressive:
+            cycles = max(2, cycles // 4)
+        rt = TkOptiX(width=W, height=H, start_now=False, progressive=progressive)
         rt.bind_device_inputs(dem_buf, dem_h, dem_w, col_buf, col_shape)
         rt.apply_scene_desc(named_scene("S1", W, H, spp_per_launch=min(frames, 64)))
         rt.set_uint("path_seg_range", 2, 4)
@@ -146,8 +208,63 @@ def facade_rates(dem_buf, dem_h, dem_w, col_buf, col_shape, W, H, cycles=8):
         out[label] = {"ms_per_cycle": round(dt * 1e3, 3), "cycles_per_s": round(1.0 / dt, 2)}
         rt.close()
     out["note"] = ("TkOptiX.render_cycle at %dx%d: launches + callbacks + RGBA8 image read back to host memory; the hit buffer "
-                   "stays on the device until _get_hit_at asks for it. Reference remarks (unnamed RTX GPU, unnamed "
+                   "stays on the device until _get_hit_at asks for it. converged_64spp = this backend's default, ONE launch of 64 "
+                   "samples and one on_launch_finished per cycle; converged_64spp_progressive = TkOptiX(progressive=True), "
+                   "PlotOptiX's min_accumulation_step=1: 64 launches of one frame, 64 image read-backs, 64 callbacks "
+                   "(moon_renderer.py:578, renderer_status.py:239), the same final image. Reference remarks (unnamed RTX GPU, unnamed "
                    "resolution): ~20 preview steps/s, ~1.5 s per converged image (moon_renderer.py:121-129)" % (W, H))
+    return out
+
+
+def numpy_baselines(args, scene, dem_buf, dem_h, dem_w, W, H, dev, direct_counts, frame):
+    """BASELINE.md section 3 / SURVEY.md 8(d): the numpy march on all the cores this box grants, cfg1 in full and a 256 x 256 crop
+    through the terminator of the timed workload at 4 spp."""
+    import copy
+    import numpy as np
+    from moonrtx_amd.renderer import synth_ldem, dem_from_ldem
+    from moonrtx_amd.scene import named_scene
+    workers = host_workers()
+    out = {"unit": "Mrays/s", "cores": workers, "host_cores": os.cpu_count(), "kind": "port",
+           "what": "oracle/numpy_march.py (numpy, float64, library trig, every march step evaluated exactly; camera ray + bisection + "
+                   "normal + one light sample with its marched shadow ray: the direct-light model, it has no path continuation), "
+                   f"multiprocessing (spawn) over row bands, {workers} worker processes"}
+    # (a) cfg1 in full: its own 5760 x 11520 DEM, 512 x 512 x 1 spp
+    w1, h1, spp1, dh1, dw1, _ = WORKLOADS["cfg1"]
+    src = synth_ldem(dh1, dw1, device=dev)
+    d1, _ = dem_from_ldem(src, dh1, dw1, 1, device=dev)
+    src.free()
+    dem1 = d1.download(np.float32, (dh1, dw1))
+    d1.free()
+    s1 = named_scene(args.scene, w1, h1, spp_per_launch=1)
+    a = cpu_baseline_numpy(s1, dem1, workers, spp1, (0, 0, w1, h1), "cfg1 in full: 512x512, 1 spp, DEM 5760x11520, direct light")
+    del dem1
+    out["cfg1"] = a
+    # (b) the timed workload's own frame: a 256 x 256 crop centred on the terminator, 4 spp
+    dem = dem_buf.download(np.float32, (dem_h, dem_w))
+    s2 = copy.copy(scene)
+    s2.path_seg_min = s2.path_seg_max = 1
+    wv = np.asarray(s2.target, float) - np.asarray(s2.eye, float); dist = float(np.linalg.norm(wv)); wv /= dist
+    uv = np.cross(wv, np.asarray(s2.up, float)); uv /= np.linalg.norm(uv)
+    vv = np.cross(uv, wv)
+    ld = np.asarray(s2.light_pos, float) - np.asarray(s2.center, float); ld /= np.linalg.norm(ld)
+    r_px = float(s2.radius) / dist / np.tan(np.radians(s2.vfov_deg) / 2) * (H / 2)      # disc radius in pixels
+    sd = np.array([ld @ uv, ld @ vv]); sd /= max(1e-9, np.linalg.norm(sd))
+    off = -r_px * float(ld @ (-wv))                       # the terminator's centre: cos(phase) disc radii towards the night side
+    ctr_dir = (np.asarray(s2.center, float) - np.asarray(s2.eye, float)) / dist
+    cx = W / 2 + (ctr_dir @ uv) / np.tan(np.radians(s2.vfov_deg) / 2) * (H / 2) + sd[0] * off
+    cy = H / 2 - (ctr_dir @ vv) / np.tan(np.radians(s2.vfov_deg) / 2) * (H / 2) - sd[1] * off
+    x0 = int(min(max(0, cx - 128), W - 256)); y0 = int(min(max(0, cy - 128), H - 256))
+    b = cpu_baseline_numpy(s2, dem, workers, 4, (x0, y0, x0 + 256, y0 + 256),
+                           f"{args.workload}: 256x256 crop at ({x0}, {y0}) through the terminator, 4 spp, DEM {dem_h}x{dem_w}, direct light")
+    out["crop"] = b
+    # scaled to the whole frame by DEM samples (the crop is all Moon, 64 % of the frame's rays are sky): the frame's direct-light
+    # evaluations as the spec defines them / the numpy march's evaluations per second
+    ref = direct_counts if direct_counts is not None else frame
+    out["value"] = round(frame["primary_rays"] / (ref["height_samples"] / b["dem_samples_per_s"]) / 1e6, 4)
+    out["sample"] = (f"whole-frame equivalent of the crop's rate: {ref['height_samples']} DEM evaluations of the "
+                     + ("direct-light " if direct_counts is not None else "") + f"frame / {b['dem_samples_per_s'] / 1e6:.2f} M numpy DEM evaluations/s "
+                     f"({b['rays']} rays, {b['dem_samples']} evaluations in {b['seconds']} s on {workers} processes); cfg1 in full: "
+                     f"{a['mrays_per_s']} Mrays/s ({a['seconds']} s)")
     return out
 
 
@@ -324,6 +441,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rays = W * H * spp
+        cfg_used = rt.config()               # the tile size the context actually runs with (16 x 16 up to two ranks, 32 x 32 beyond)
         wide = "true" if (dem_h + 4) * (dem_w + 4) * 8 > 0xFFFFFFFF else "false"
         queue = seg[1] > 1 and not args.inwave_paths and paths_ms > 0.0   # small launches keep their paths in the wave (MOONRT_PATH_QUEUE_MIN)
         # ---- roofline.  Bytes are ALGORITHMIC; time is the HIP-event duration of the kernels.
@@ -331,14 +449,19 @@ def main():
         frame_bytes = algorithmic_bytes(counted, W, H) + px_adj
         frame_bytes_nom = algorithmic_bytes(counted, W, H, nominal=True) + px_adj
         kernels = {}
-        if queue and direct_counts is not None:
-            a_bytes = algorithmic_bytes(direct_counts, W, H)
+        if queue and world == 1:
+            # the counted frame says what EACH kernel evaluated (MrtxStats::camera_* = render_kernel's own share, trial segment
+            # included; the rest is path_kernel's) -- round 3 borrowed the direct frame's counts for the render kernel
+            cam = {"dem_fetches": counted["camera_dem_fetches"], "mip_fetches": counted["camera_mip_fetches"],
+                   "colour_fetches": counted["camera_colour_fetches"], "background_fetches": counted["camera_background_fetches"],
+                   "height_samples": counted["camera_height_samples"]}
+            a_bytes = algorithmic_bytes(cam, W, H)
             kernels["render_kernel<%d, false, %s, 2, false>" % (S, wide)] = {
                 "ms": round(primary_ms, 3), "algorithmic_bytes": int(a_bytes),
                 "achieved": round(a_bytes / (primary_ms * 1e-3) / 1e9, 1), "frac": round(a_bytes / (primary_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "counts": {k: int(v) for k, v in cam.items()},
                 "does": "camera ray, march, first vertex, light sample + shadow march, roulette + continuation ray + its first "
-                        "segment, hand-over records; its algorithmic bytes are those of the direct frame -- a lower bound: the "
-                        "evaluations of the trial segment, which this kernel performs as well, are booked with the path stage in this split"}
+                        "segment, hand-over records; algorithmic bytes from this kernel's OWN counters in the counted frame"}
             p_bytes = frame_bytes - a_bytes
             kernels["path_kernel<false, %s> + resolve_paths_kernel<%d>" % (wide, S)] = {
                 "ms": round(paths_ms, 3), "algorithmic_bytes": int(p_bytes),
@@ -384,6 +507,7 @@ def main():
             if util is not None:
                 lim = "hbm" if util >= 0.6 else ("valu+latency" if (v.get("valu_issue_frac") or 0) >= 0.3 else "latency")
             return {"hbm_bytes": int(v["hbm_bytes"]) if v.get("hbm_bytes") else None, "hbm_utilisation": None if util is None else round(util, 4),
+                    "hbm_bytes_note": "FETCH_SIZE / WRITE_SIZE = traffic leaving the L2s: it INCLUDES what the 256 MB Infinity Cache serves (MI355X_MICROARCH.md), so 'hbm' here means the memory side of the L2, an upper bound on DRAM traffic",
                     "valu_issue_frac": v.get("valu_issue_frac"), "lanes_per_valu_inst": v.get("lanes_per_valu"), "l2_hit": v.get("l2_hit"),
                     "profile_kernel_ms": v.get("avg_ms"), "limited_by": lim}
 
@@ -396,14 +520,22 @@ def main():
                 "kernel": dom, "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": int(dom_bytes),
                 "limited_by": (measured(pk) or {}).get("limited_by"),
                 "limiter": "`bound` names the roofline the fraction is priced against (the HBM read roofline BASELINE.json asks for); what the PMC "
-                           "counters say limits each kernel is `limited_by` (here and per kernel under `kernels`): hbm = measured HBM traffic >= 0.6 "
-                           "of peak, valu+latency = VALU issue >= 0.3 with HBM far from its peak (dependent-load rounds x the waves a SIMD holds)",
+                           "counters say limits each kernel is `limited_by` (here and per kernel under `kernels`): hbm = measured traffic beyond the L2s "
+                           "(FETCH_SIZE: Infinity-Cache hits included, so an upper bound on DRAM traffic) >= 0.6 of the HBM peak, valu+latency = VALU "
+                           "issue >= 0.3 with that traffic far from the peak (VALU issue + dependent-load rounds)",
                 "valu_issue_frac": None if pk is None else pk.get("valu_issue_frac"),
                 "hbm_utilisation": None if pk is None else round(pk["hbm_bytes"] / (pk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "lanes_per_valu_inst": None if pk is None else pk.get("lanes_per_valu"),
                 "l2_hit": None if pk is None else pk.get("l2_hit"),
                 "profile": prof_note,
                 "profile_kernel_ms": None if pk is None else pk["avg_ms"],
+                # SURVEY.md 8(d) read literally: 16 B for every DEM evaluation the march DEFINES (the oracle's count), whether or not a
+                # kernel had to perform it.  > 1 means the kernels did not do the counted work: the max-mip / horizon bounds prove
+                # `skip_ratio` of the defined evaluations unnecessary (results and counters identical with MRTX_F_NO_SKIP, tested)
+                "frac_literal": round(frame_bytes_nom / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_literal_note": "whole frame, every evaluation the march defines at 16 B (SURVEY.md 8(d) literally) / frame kernel time / 8 TB/s; "
+                                     "exceeds 1 because only dem_fetches of the height_samples are performed",
+                "skip_ratio": round(1.0 - frame["dem_fetches"] / max(1, frame["height_samples"]), 4),
                 "frame": {"kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(frame_bytes),
                           "achieved": round(frame_bytes / (kernel_ms * 1e-3) / 1e9, 1),
                           "frac": round(frame_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -427,8 +559,9 @@ def main():
                                    + f", scene {args.scene}" + (f" zoomed on the terminator (vfov {args.zoom} deg)" if args.zoom > 0 else "")
                                    + f", path_seg_range {seg}"
                                    + (" = the reference's setting (moon_renderer.py:583)" if seg == (2, 4) else ""),
-                       "parallelism": f"image tiles 32x32 dealt round-robin (2-D lattice) over {world} GPU(s)"
-                                      + ("" if world == 1 else ", packed float4 radiance + hit tiles of the active tiles gathered to rank 0 by torch.distributed.gather over "
+                       "parallelism": f"image tiles {cfg_used['tile_w']}x{cfg_used['tile_h']} dealt round-robin (2-D lattice) over {world} GPU(s)"
+                                      + ("" if world == 1 else (", packed float4 radiance" + (" + hit" if gather.with_hits else "") + " tiles of the active tiles ("
+                                         + ("32" if gather.with_hits else "16") + " B per pixel) gathered to rank 0 by torch.distributed.gather over ")
                                          + ("RCCL (xGMI)" if backend == "nccl" else f"{backend} (staged through host memory: a rehearsal, not the production transport)")
                                          + f" in {int((getattr(gather, 'last_timing', None) or {}).get('parts', 1))} part(s), all but the last overlapped with rendering"),
                        "march": "step 5e-3, eps 3e-4, scene_epsilon 1e-4, 1 light sample + shadow ray per path vertex, "
@@ -443,6 +576,9 @@ def main():
                                     "asynchronous gathers + device synchronise); unpack_ms = mrtx_unpack_all on rank 0"},
             "kernel_ms": round(kernel_ms, 3), "primary_ms": round(primary_ms, 3), "paths_ms": round(paths_ms, 3),
             "frame_counts": frame,
+            "hit_samples_per_s": round(frame["primary_hits"] / (ms_per_step * 1e-3), 1),
+            "value_note": "1 ray = 1 primary camera sample (SURVEY.md 8(d)): the %.0f %% of them that the host-side sky cull proves black are "
+                          "counted and never traced; hit_samples_per_s counts the samples that met the Moon" % (100.0 * (1.0 - frame["primary_hits"] / rays)),
             "bytes_per_ray": round(algorithmic_bytes(frame, W, H) / rays, 2),
             "bytes_per_ray_nominal": round(algorithmic_bytes(frame, W, H, nominal=True) / rays, 2),
             "roofline": roof,
@@ -460,6 +596,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, dem_buf, (dem_h, dem_w), col_buf, col_shape, frame,
                                                args.cpu_budget_s)
+            try:
+                out["cpu_baseline_numpy"] = numpy_baselines(args, scene, dem_buf, dem_h, dem_w, W, H, dev, direct_counts, frame)
+            except Exception as e:     # a side figure must not take the headline down
+                out["cpu_baseline_numpy"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
     rt.close()

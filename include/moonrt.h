@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRTX_ABI_VERSION 6
+#define MRTX_ABI_VERSION 7
 
 enum {
     MRTX_OK = 0,
@@ -94,6 +94,11 @@ typedef struct MrtxStats {
                                      (0 unless path_seg_max > 1 and the queue-based path stage is in use)      */
     uint32_t launches;
     uint32_t reserved;
+    /* ABI 7: the share of the counters above that render_kernel (the camera-ray stage: camera ray, first vertex, its shadow ray,
+     * and with the path queue the FIRST segment of the continuation ray) performed itself; the rest was performed by path_kernel.
+     * With the paths inside the render wave (or path_seg_max <= 1) these equal the totals.  bench.py prices each kernel's
+     * algorithmic bytes with its own counts. */
+    uint64_t camera_height_samples, camera_dem_fetches, camera_mip_fetches, camera_colour_fetches, camera_background_fetches;
 } MrtxStats;
 
 /* TkOptiX(width, height, ...) -- moon_renderer.py:571-575.  Allocates accumulation + hit buffers. */
@@ -102,6 +107,9 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out);
 void mrtx_destroy(mrtx_ctx* ctx);
 const char* mrtx_last_error(mrtx_ctx* ctx);
 int mrtx_abi_version(void);
+/* The configuration the context runs with: what mrtx_create was given, with the defaults filled in (tile_w / tile_h: 16 x 16
+ * for world <= 2, 32 x 32 from four ranks up) -- so that a caller reports the tiling that was actually used. */
+int mrtx_get_config(mrtx_ctx* ctx, MrtxConfig* out);
 
 /* rt.set_displacement("moon", elevation, refresh=False) -- moon_renderer.py:624.
  * `host` is the float32 (h, w) array load_elevation_data returns (data_loader.py:166-247):
@@ -191,6 +199,12 @@ int mrtx_samples_done(mrtx_ctx* ctx, uint32_t* out);
  * A rank packs the tiles it owns (linear float4 radiance followed by float4 hits) into a compact
  * device buffer the caller provides (e.g. a torch tensor handed to an RCCL gather), and rank 0
  * scatters the gathered buffers back into frame order. */
+/* Whether the hit buffer travels with the radiance (default 1: a packed slot is one tile of float4 sums followed by one tile of
+ * float4 hits, 32 B per pixel).  0: sums only, 16 B per pixel -- the exchange moves the final linear framebuffer and nothing
+ * else; the root's hit buffer then holds its own tiles only, and a pick (rt._get_hit_at(x, y), one texel per mouse event,
+ * moon_renderer.py:1137-1142) is served by mrtx_read_hit on the rank that owns the pixel (moonrtx_amd/dist.py: FrameGather.hit_at).
+ * Must be set alike on every rank; changes mrtx_shard_bytes* and the layout pack / unpack use. */
+int mrtx_set_gather_hits(mrtx_ctx* ctx, int32_t on);
 int mrtx_shard_bytes(mrtx_ctx* ctx, int32_t rank, uint64_t* out);   /* upper bound of a packed buffer (all tiles) */
 /* Bytes the exchange moves per rank for the scene as it stands.  While the host-side sky cull is in force (no
  * environment map, no overlay geometry, MRTX_F_NO_CULL clear) only the tiles the cull keeps travel: every rank

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOONRT_LIB") or os.path.join(_HERE, "libmoonrt.so")   # MOONRT_LIB: A/B builds only
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MrtxConfig(C.Structure):
@@ -31,7 +31,10 @@ class MrtxStats(C.Structure):
                 ("background_fetches", C.c_uint64), ("dem_fetches", C.c_uint64), ("mip_fetches", C.c_uint64), ("bounce_rays", C.c_uint64),
                 ("bounce_sun_hits", C.c_uint64),
                 ("kernel_ms", C.c_double), ("primary_ms", C.c_double), ("paths_ms", C.c_double),
-                ("launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("launches", C.c_uint32), ("reserved", C.c_uint32),
+                # ABI 7: render_kernel's own share of the counters (the rest is path_kernel's)
+                ("camera_height_samples", C.c_uint64), ("camera_dem_fetches", C.c_uint64), ("camera_mip_fetches", C.c_uint64),
+                ("camera_colour_fetches", C.c_uint64), ("camera_background_fetches", C.c_uint64)]
 
 
 F_COUNT_STATS = 1
@@ -48,6 +51,8 @@ _VP = C.c_void_p
 # name -> (restype, argtypes): every symbol include/moonrt.h declares
 SIGNATURES = {
     "mrtx_abi_version": (C.c_int, []),
+    "mrtx_get_config": (C.c_int, [_VP, C.POINTER(MrtxConfig)]),
+    "mrtx_set_gather_hits": (C.c_int, [_VP, C.c_int32]),
     "mrtx_create": (C.c_int, [C.POINTER(MrtxConfig), C.POINTER(_VP)]),
     "mrtx_destroy": (None, [_VP]),
     "mrtx_last_error": (C.c_char_p, [_VP]),

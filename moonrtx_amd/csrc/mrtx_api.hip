@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -28,10 +29,10 @@ hipError_t mrtx_launch_resolve_rgb16(const float* accum, uint16_t* out, int64_t 
                                      const float* T16, hipStream_t st);
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
                             int tiles_x, int n_tiles, int rank, int world, int slot0, int slots, const int32_t* list, int shift,
-                            hipStream_t st);
+                            int with_hits, hipStream_t st);
 hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
                               int tiles_x, int n_tiles, int src_rank, int world, int slots, const int32_t* list, int shift,
-                              hipStream_t st);
+                              int with_hits, hipStream_t st);
 hipError_t mrtx_launch_zero_tiles(float* accum, float* hits, const int32_t* tiles, int n, int W, int H, int tw, int th,
                                   int tiles_x, int shift, hipStream_t st);
 hipError_t mrtx_launch_ldem(const int16_t* src, float* dst, int h, int w, int d, unsigned int* max_bits,
@@ -67,6 +68,8 @@ struct mrtx_ctx {
     // 2.41, 4 spp 3.42 / 3.16; cfg1 0.33 / 0.53; tools/spp_sweep.py).  MOONRT_PATH_QUEUE_MIN overrides (0 = always the queue).
     uint64_t path_queue_min = 8000000ull;
     bool path_fallback_said = false;     // the fall-back to in-wave paths (no memory for the records) was reported
+    uint64_t path_nomem_chunks = 0;      // a hand-over allocation of this many chunks failed: not retried until less is needed or mrtx_reset_accum
+    bool gather_hits = true;             // mrtx_set_gather_hits: the hit buffer travels with the radiance
     bool path_alloc_fail_test = false;   // MOONRT_TEST_PATH_NOMEM=1: test hook, the hand-over allocation "fails"
     int path_refill = 32, path_segmin = 16, path_hitmin = 16, path_waves_env = 0;   // cfg3 sweep: (8,24,16) 16.2 ms, (24,24,16) 14.7, (32,16,16) 14.5, (48,24,16) 21.5
     float* accum = nullptr;
@@ -130,6 +133,49 @@ static hipError_t h2d(mrtx_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 
 namespace {
+
+// Streams and events are POOLED per device and never destroyed while the process lives (MOONRT_POOL_STREAMS=0 switches back to
+// create / destroy per context).  A context is cheap and short-lived in the tests (hundreds per process); the pool saves two
+// runtime calls per object and, more to the point, keeps the HIP runtime's completion threads from ever working on a stream or
+// event whose owner has gone (round 4: the harness's input guard caught a word of a host array being decremented by one while
+// only the runtime's own threads could have been writing, profiles/r04_seed601_case49.md).
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> streams[16];
+    std::vector<hipEvent_t> events[16];
+};
+StreamPool& pool() { static StreamPool* p = new StreamPool(); return *p; }     // leaked on purpose: outlives every context
+// MOONRT_POOL_STREAMS: unset / 1 = pool both (default), 0 = neither, 2 = streams only, 3 = events only (the last two: diagnosis)
+int pool_mode() { static const int m = std::getenv("MOONRT_POOL_STREAMS") ? std::atoi(std::getenv("MOONRT_POOL_STREAMS")) : 1; return m; }
+bool pool_streams() { return pool_mode() == 1 || pool_mode() == 2; }
+bool pool_events() { return pool_mode() == 1 || pool_mode() == 3; }
+
+hipError_t get_stream(int dev, hipStream_t* out) {
+    if (pool_streams() && dev >= 0 && dev < 16) {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto& v = pool().streams[dev];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void put_stream(int dev, hipStream_t st) {
+    if (!st) return;
+    if (pool_streams() && dev >= 0 && dev < 16) { std::lock_guard<std::mutex> g(pool().mu); pool().streams[dev].push_back(st); }
+    else (void)hipStreamDestroy(st);
+}
+hipError_t get_event(int dev, hipEvent_t* out) {
+    if (pool_events() && dev >= 0 && dev < 16) {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto& v = pool().events[dev];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipEventCreate(out);
+}
+void put_event(int dev, hipEvent_t ev) {
+    if (!ev) return;
+    if (pool_events() && dev >= 0 && dev < 16) { std::lock_guard<std::mutex> g(pool().mu); pool().events[dev].push_back(ev); }
+    else (void)hipEventDestroy(ev);
+}
 
 int fail(mrtx_ctx* c, int code, const char* fmt, ...) {
     if (c) {
@@ -269,7 +315,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     f.tile_w = c->cfg.tile_w; f.tile_h = c->cfg.tile_h;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.tile_shift = c->tile_shift;
     f.rank = c->cfg.rank; f.world = c->cfg.world; f.n_local_tiles = c->n_local;
-    k.accum = c->accum; k.hits = c->hits; k.stats = c->stats_dev;
+    k.accum = c->accum; k.hits = c->hits; k.stats = c->stats_dev; k.stats_paths = c->stats_dev + 16;
     f.tile_list = nullptr; f.n_active = c->n_local;
 }
 
@@ -446,6 +492,12 @@ extern "C" {
 
 int mrtx_abi_version(void) { return MRTX_ABI_VERSION; }
 
+int mrtx_get_config(mrtx_ctx* c, MrtxConfig* out) {
+    if (!c || !out) return MRTX_E_INVALID;
+    *out = c->cfg;      // mrtx_create filled the defaults in
+    return MRTX_OK;
+}
+
 void mrtx_default_params(MrtxParams* p) {
     if (!p) return;
     std::memset(p, 0, sizeof *p);
@@ -499,18 +551,18 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
     *out = c;  // from here on the caller can read mrtx_last_error and must destroy
     const size_t fb = (size_t)cfg->width * cfg->height * 16;
     HIPCHK(c, hipSetDevice(cfg->device));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreate(&c->ev0));
-    HIPCHK(c, hipEventCreate(&c->ev1));
+    HIPCHK(c, get_stream(cfg->device, &c->stream));
+    HIPCHK(c, get_event(cfg->device, &c->ev0));
+    HIPCHK(c, get_event(cfg->device, &c->ev1));
     HIPCHK(c, hipMalloc((void**)&c->accum, fb));
     HIPCHK(c, hipMalloc((void**)&c->hits, fb));
     HIPCHK(c, hipMalloc(&c->scratch, fb));
-    HIPCHK(c, hipMalloc((void**)&c->stats_dev, 16 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc((void**)&c->stats_dev, 32 * sizeof(unsigned long long)));   // [0..15] render_kernel (+ watchdog), [16..31] path_kernel
     HIPCHK(c, hipMalloc((void**)&c->cold_dev, sizeof(FrameCold)));
     HIPCHK(c, hipMalloc((void**)&c->tile_list_dev, (size_t)(c->n_local > 0 ? c->n_local : 1) * sizeof(int32_t)));
     HIPCHK(c, hipMemsetAsync(c->accum, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->hits, 0, fb, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 32 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MRTX_OK;
 }
@@ -537,16 +589,16 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->path_npaths) (void)hipFree(c->path_npaths);
     if (c->path_ctr) (void)hipFree(c->path_ctr);
     if (c->wd_host) (void)hipHostFree(c->wd_host);
-    for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->evs) put_event(c->cfg.device, e);
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
     if (c->hmip) (void)hipFree(c->hmip);
     if (c->color) (void)hipFree(c->color);
     if (c->bg) (void)hipFree(c->bg);
     if (c->overlay) (void)hipFree(c->overlay);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    put_event(c->cfg.device, c->ev0);
+    put_event(c->cfg.device, c->ev1);
+    put_stream(c->cfg.device, c->stream);      // synchronised above
     delete c;
 }
 
@@ -745,6 +797,7 @@ int mrtx_set_capsules(mrtx_ctx* c, const float* caps12, int32_t n) {
 int mrtx_reset_accum(mrtx_ctx* c) {
     if (!c) return MRTX_E_INVALID;
     c->blocks_done = 0;
+    c->path_nomem_chunks = 0;            // a new accumulation cycle may try the hand-over allocation again
     return MRTX_OK;
 }
 
@@ -837,7 +890,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         culled_px = 0;
         c->tile_dirty.assign((size_t)c->n_local, 1);
     }
-    if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 16 * sizeof(unsigned long long), c->stream));
+    if (stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 32 * sizeof(unsigned long long), c->stream));
     // D6 (path_seg_max > 1): by default the path continues in path_kernel behind a queue (mode 2);
     // MRTX_F_INWAVE_PATHS keeps it inside the render wave (mode 1) -- same result bit for bit, slower.
     const int S = (int)c->prm.spp_per_launch;
@@ -864,7 +917,8 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     int n_sub = 1;
     auto fall_back = [&](const char* why) {
         if (!c->path_fallback_said) {
-            std::fprintf(stderr, "libmoonrt: %s -- this context keeps its paths inside the render wave (same result, slower)\n", why);
+            std::fprintf(stderr, "libmoonrt: %s -- frames of this size keep their paths inside the render wave (same result, slower); "
+                                 "retried after mrtx_reset_accum or when a frame needs less\n", why);
             c->path_fallback_said = true;
         }
         mode = 1;
@@ -893,6 +947,8 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     }
     if (chunks * 64ull > 0xFFFFFFFFull) {
         fall_back("the frame holds more wave-jobs than one deferred-path launch can index");
+    } else if (chunks > c->path_cap && c->path_nomem_chunks != 0 && chunks >= c->path_nomem_chunks) {
+        mode = 1;      // an allocation of this size failed before: do not free and retry three multi-gigabyte hipMallocs per frame
     } else if (chunks > c->path_cap) {
         if (c->path_rec) { HIPCHK(c, hipFree(c->path_rec)); c->path_rec = nullptr; }
         if (c->path_meta) { HIPCHK(c, hipFree(c->path_meta)); c->path_meta = nullptr; }
@@ -906,9 +962,11 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             if (c->path_rec) { (void)hipFree(c->path_rec); c->path_rec = nullptr; }
             if (c->path_meta) { (void)hipFree(c->path_meta); c->path_meta = nullptr; }
             if (c->path_npaths) { (void)hipFree(c->path_npaths); c->path_npaths = nullptr; }
+            c->path_nomem_chunks = chunks;                              // latched until less is needed or mrtx_reset_accum
             fall_back("no device memory for the hand-over records");
         } else {
             c->path_cap = chunks;
+            c->path_nomem_chunks = 0;
         }
     }
     const size_t n = (size_t)c->path_cap * 64;
@@ -961,7 +1019,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         }
         const int nw = c->path_waves_env ? c->path_waves_env : c->path_waves[wi];
         const size_t n_ev = (size_t)n_blocks * (size_t)n_sub * 3;
-        while (c->evs.size() < n_ev) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->evs.push_back(e); }
+        while (c->evs.size() < n_ev) { hipEvent_t e; HIPCHK(c, get_event(c->cfg.device, &e)); c->evs.push_back(e); }
         for (int32_t b = 0; b < n_blocks && f.n_active > 0; b++) {
             for (int s = 0; s < n_sub; s++) {
                 hipEvent_t* ev = &c->evs[((size_t)b * (size_t)n_sub + (size_t)s) * 3];
@@ -1022,8 +1080,11 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         out->paths_ms = paths_ms;
         out->launches = launches;
         if (stats) {
-            unsigned long long h[16];
+            unsigned long long h[32];
             HIPCHK(c, hipMemcpy(h, c->stats_dev, sizeof h, hipMemcpyDeviceToHost));
+            out->camera_height_samples = h[3]; out->camera_dem_fetches = h[6]; out->camera_mip_fetches = h[7];
+            out->camera_colour_fetches = h[4]; out->camera_background_fetches = h[5];
+            for (int i = 0; i < 15; i++) h[i] += h[16 + i];          // totals = render_kernel's + path_kernel's
             out->primary_rays = h[0] + (part == 0 ? culled_px : 0) * (uint64_t)c->prm.spp_per_launch * (uint64_t)n_blocks;
             out->primary_hits = h[1]; out->shadow_rays = h[2];
             out->height_samples = h[3]; out->colour_fetches = h[4]; out->background_fetches = h[5];
@@ -1177,16 +1238,21 @@ static void mark_peer_written(mrtx_ctx* c, int src_rank) {
     }
 }
 
+int mrtx_set_gather_hits(mrtx_ctx* c, int32_t on) {
+    if (!c) return MRTX_E_INVALID;
+    c->gather_hits = on != 0;
+    return MRTX_OK;
+}
 int mrtx_shard_bytes(mrtx_ctx* c, int32_t rank, uint64_t* out) {
     if (!c || !out || rank < 0 || rank >= c->cfg.world) return MRTX_E_INVALID;
-    *out = (uint64_t)c->slots * c->cfg.tile_w * c->cfg.tile_h * 32ull;  // equal for every rank (padded): the upper bound
+    *out = (uint64_t)c->slots * c->cfg.tile_w * c->cfg.tile_h * (c->gather_hits ? 32ull : 16ull);  // equal for every rank (padded): the upper bound
     return MRTX_OK;
 }
 int mrtx_shard_bytes_active(mrtx_ctx* c, uint64_t* out) {
     if (!c || !out) return MRTX_E_INVALID;
     const int rc = gather_layout(c);
     if (rc != MRTX_OK) return rc;
-    *out = (uint64_t)c->act_slots * c->cfg.tile_w * c->cfg.tile_h * 32ull;
+    *out = (uint64_t)c->act_slots * c->cfg.tile_w * c->cfg.tile_h * (c->gather_hits ? 32ull : 16ull);
     return MRTX_OK;
 }
 int mrtx_pack_shard(mrtx_ctx* c, void* dev_dst, void* hip_stream) { return mrtx_pack_part(c, dev_dst, 0, 1, nullptr, nullptr, hip_stream); }
@@ -1207,8 +1273,8 @@ int mrtx_pack_part(mrtx_ctx* c, void* dev_dst, int32_t part, int32_t n_parts, ui
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     HIPCHK(c, mrtx_launch_pack(c->accum, c->hits, dev_dst, c->cfg.width, c->cfg.height, c->cfg.tile_w, c->cfg.tile_h,
                                c->tiles_x, c->n_tiles, c->cfg.rank, c->cfg.world, a, b - a, layout_list(c, c->cfg.rank),
-                               c->tile_shift, st));
-    const uint64_t slot_bytes = (uint64_t)c->cfg.tile_w * c->cfg.tile_h * 32ull;
+                               c->tile_shift, c->gather_hits ? 1 : 0, st));
+    const uint64_t slot_bytes = (uint64_t)c->cfg.tile_w * c->cfg.tile_h * (c->gather_hits ? 32ull : 16ull);
     if (byte_off) *byte_off = (uint64_t)a * slot_bytes;
     if (byte_len) *byte_len = (uint64_t)(b - a) * slot_bytes;
     if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
@@ -1234,7 +1300,7 @@ int mrtx_unpack_shard(mrtx_ctx* c, int32_t src_rank, const void* dev_src, void* 
     if (hip_stream) HIPCHK(c, hipStreamSynchronize(c->stream));   // the stale-tile clear ran on the context's stream
     HIPCHK(c, mrtx_launch_unpack(c->accum, c->hits, dev_src, c->cfg.width, c->cfg.height, c->cfg.tile_w,
                                  c->cfg.tile_h, c->tiles_x, c->n_tiles, src_rank, c->cfg.world, c->act_slots,
-                                 layout_list(c, src_rank), c->tile_shift, st));
+                                 layout_list(c, src_rank), c->tile_shift, c->gather_hits ? 1 : 0, st));
     mark_peer_written(c, src_rank);
     if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
     return MRTX_OK;
@@ -1252,7 +1318,7 @@ int mrtx_unpack_all(mrtx_ctx* c, const void* const* dev_srcs, int32_t n) {
         if (!dev_srcs[r]) return fail(c, MRTX_E_INVALID, "missing shard of rank %d", r);
         HIPCHK(c, mrtx_launch_unpack(c->accum, c->hits, dev_srcs[r], c->cfg.width, c->cfg.height, c->cfg.tile_w,
                                      c->cfg.tile_h, c->tiles_x, c->n_tiles, r, c->cfg.world, c->act_slots,
-                                     layout_list(c, r), c->tile_shift, c->stream));
+                                     layout_list(c, r), c->tile_shift, c->gather_hits ? 1 : 0, c->stream));
         mark_peer_written(c, r);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));

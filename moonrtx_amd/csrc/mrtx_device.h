@@ -76,7 +76,8 @@ struct FrameCold {
     // not occupy SGPRs (and get spilled) across the march loops
     float* accum;           // W*H float4: running sums r,g,b,coverage
     float* hits;            // W*H float4: x,y,z,d of sample 0 of the last block
-    unsigned long long* stats;  // 10 counters, see MrtxStats
+    unsigned long long* stats;  // 10 counters, see MrtxStats (render_kernel's; [15] = path_kernel's watchdog)
+    unsigned long long* stats_paths;   // the same counters as path_kernel adds them (MrtxStats::camera_* = the render kernel's share)
     // horizon mip (horizon_kend in mrtx_kernels.hip): hm_h x hm_w cells of 2^hm_shift texels, or null
     const float* hmip;
     int32_t hm_h, hm_w, hm_shift;

@@ -2152,7 +2152,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
             uint32_t t = cnt[i];
 #pragma unroll
             for (int k = 1; k < 64; k <<= 1) t += __shfl_xor(t, k, 64);
-            if (lane == 0 && t != 0u) atomicAdd(&CF(f)->stats[i], (unsigned long long)t);
+            if (lane == 0 && t != 0u) atomicAdd(&CF(f)->stats_paths[i], (unsigned long long)t);
         }
     }
 }
@@ -2283,7 +2283,7 @@ __global__ void resolve_rgb16_kernel(const float4* __restrict__ accum, uint16_t*
 __global__ void pack_shard_kernel(const float4* __restrict__ accum, const float4* __restrict__ hits,
                                   float4* __restrict__ dst, int W, int H, int tile_w, int tile_h, int tiles_x,
                                   int n_tiles, int rank, int world, int slot0, int slots, const int32_t* __restrict__ list,
-                                  int shift) {
+                                  int shift, int with_hits) {
     const int tile_px = tile_w * tile_h;
     const int64_t total = (int64_t)slots * tile_px;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -2295,17 +2295,17 @@ __global__ void pack_shard_kernel(const float4* __restrict__ accum, const float4
             int tx, ty;
             mrtx_tile_xy(t, tiles_x, shift, tx, ty);
             const int x = tx * tile_w + r % tile_w, y = ty * tile_h + r / tile_w;
-            if (x < W && y < H) { a = accum[(int64_t)y * W + x]; h = hits[(int64_t)y * W + x]; }
+            if (x < W && y < H) { a = accum[(int64_t)y * W + x]; if (with_hits) h = hits[(int64_t)y * W + x]; }
         }
-        const int64_t o = (int64_t)slot * 2 * tile_px + r;
+        const int64_t o = (int64_t)slot * (with_hits ? 2 : 1) * tile_px + r;     // a slot = sums tile [+ hits tile]
         dst[o] = a;
-        dst[o + tile_px] = h;
+        if (with_hits) dst[o + tile_px] = h;
     }
 }
 __global__ void unpack_shard_kernel(float4* __restrict__ accum, float4* __restrict__ hits,
                                     const float4* __restrict__ src, int W, int H, int tile_w, int tile_h,
                                     int tiles_x, int n_tiles, int src_rank, int world, int slots,
-                                    const int32_t* __restrict__ list, int shift) {
+                                    const int32_t* __restrict__ list, int shift, int with_hits) {
     const int tile_px = tile_w * tile_h;
     const int64_t total = (int64_t)slots * tile_px;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -2316,8 +2316,8 @@ __global__ void unpack_shard_kernel(float4* __restrict__ accum, float4* __restri
         int tx, ty;
         mrtx_tile_xy(t, tiles_x, shift, tx, ty);
         const int x = tx * tile_w + r % tile_w, y = ty * tile_h + r / tile_w;
-        const int64_t o = (int64_t)slot * 2 * tile_px + r;
-        if (x < W && y < H) { accum[(int64_t)y * W + x] = src[o]; hits[(int64_t)y * W + x] = src[o + tile_px]; }
+        const int64_t o = (int64_t)slot * (with_hits ? 2 : 1) * tile_px + r;
+        if (x < W && y < H) { accum[(int64_t)y * W + x] = src[o]; if (with_hits) hits[(int64_t)y * W + x] = src[o + tile_px]; }
     }
 }
 
@@ -2770,20 +2770,20 @@ hipError_t mrtx_launch_resolve_rgb16(const float* accum, uint16_t* out, int64_t 
 }
 hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, int W, int H, int tw, int th,
                             int tiles_x, int n_tiles, int rank, int world, int slot0, int slots, const int32_t* list, int shift,
-                            hipStream_t st) {
+                            int with_hits, hipStream_t st) {
     if (slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(mrtx::pack_shard_kernel, dim3(grid_for((int64_t)slots * tw * th)), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(accum), reinterpret_cast<const float4*>(hits),
-                       reinterpret_cast<float4*>(dst), W, H, tw, th, tiles_x, n_tiles, rank, world, slot0, slots, list, shift);
+                       reinterpret_cast<float4*>(dst), W, H, tw, th, tiles_x, n_tiles, rank, world, slot0, slots, list, shift, with_hits);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
                               int tiles_x, int n_tiles, int src_rank, int world, int slots, const int32_t* list, int shift,
-                              hipStream_t st) {
+                              int with_hits, hipStream_t st) {
     if (slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(mrtx::unpack_shard_kernel, dim3(grid_for((int64_t)slots * tw * th)), dim3(256), 0, st,
                        reinterpret_cast<float4*>(accum), reinterpret_cast<float4*>(hits),
-                       reinterpret_cast<const float4*>(src), W, H, tw, th, tiles_x, n_tiles, src_rank, world, slots, list, shift);
+                       reinterpret_cast<const float4*>(src), W, H, tw, th, tiles_x, n_tiles, src_rank, world, slots, list, shift, with_hits);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_zero_tiles(float* accum, float* hits, const int32_t* tiles, int n, int W, int H, int tw, int th,

@@ -40,6 +40,13 @@ def tile_xy(t, tiles_x, shift):
     return (c - shift * ty) % tiles_x, ty
 
 
+def tile_owner(x, y, width, tile, world):
+    """Rank that renders pixel (x, y): its tile's number (mrtx_tile_id: raster order with the per-row cyclic shift) mod world."""
+    tiles_x = (width + tile[0] - 1) // tile[0]
+    tx, ty = x // tile[0], y // tile[1]
+    return (ty * tiles_x + (tx + tile_shift(world) * ty) % tiles_x) % world
+
+
 def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -86,11 +93,18 @@ class FrameGather:
     `renderer` needs shard_bytes(), pack_shard(ptr), unpack_shard(src_rank, ptr), rank, world -- the
     MoonRT surface (mrtx_shard_bytes / mrtx_pack_shard / mrtx_unpack_shard in include/moonrt.h)."""
 
-    def __init__(self, renderer, device):
+    def __init__(self, renderer, device, with_hits=False):
+        """`with_hits` = False (default): the exchange moves the final linear framebuffer only, 16 bytes per pixel -- what the
+        north star asks the gather for; the facade reads ONE hit texel per mouse event (moon_renderer.py:1137-1142), which
+        `hit_at()` fetches from the rank that owns the pixel.  True: the float4 hit tiles travel with the radiance (32 bytes per
+        pixel) and rank 0 holds the whole hit buffer after every frame."""
         import torch
         self.torch = torch
         self.r = renderer
         self.rank, self.world = renderer.rank, renderer.world
+        self.with_hits = bool(with_hits) or self.world == 1
+        if hasattr(renderer, "set_gather_hits"):
+            renderer.set_gather_hits(self.with_hits)
         self.nbytes = renderer.shard_bytes()
         self.send = torch.empty(self.nbytes // 4, dtype=torch.float32, device=device)
         self.recv = None
@@ -151,6 +165,23 @@ class FrameGather:
             t_unpack = time.perf_counter() - t0
         self.last_timing = {"parts": P, "pack_ms": t_pack * 1e3, "gather_wait_ms": t_wait * 1e3, "unpack_ms": t_unpack * 1e3}
         return total
+
+    def hit_at(self, x, y):
+        """rt._get_hit_at(x, y) on a sharded frame: (hx, hy, hz, hd) of pixel (x, y), on EVERY rank (a collective: all ranks call
+        it with the same pixel).  The owner of the pixel's tile reads the one texel (mrtx_read_hit, 16 bytes over PCIe) and
+        broadcasts it; with `with_hits` rank 0 already holds it but the owner's copy is the same bits."""
+        r = self.r
+        if self.world == 1:
+            return r.read_hit(x, y)
+        import torch.distributed as dist
+        cfg = r.config()
+        owner = tile_owner(int(x), int(y), cfg["width"], (cfg["tile_w"], cfg["tile_h"]), self.world)
+        dev = "cpu" if dist.get_backend() == "gloo" else self.send.device
+        t = self.torch.zeros(4, dtype=self.torch.float32, device=dev)
+        if self.rank == owner:
+            t.copy_(self.torch.tensor(r.read_hit(x, y), dtype=self.torch.float32))
+        dist.broadcast(t, src=owner)
+        return tuple(float(v) for v in t.cpu())
 
     def gather(self):
         """After every rank has rendered: bring all tiles to rank 0's framebuffer."""

@@ -240,7 +240,18 @@ class MoonRT:
         self._check(self._lib.mrtx_read_hits(self._ctx, out.ctypes.data), "mrtx_read_hits")
         return out
 
+    def config(self):
+        """The configuration the context runs with, defaults filled in (mrtx_get_config): device, width, height, rank, world,
+        tile_w, tile_h."""
+        cfg = MrtxConfig()
+        self._check(self._lib.mrtx_get_config(self._ctx, C.byref(cfg)), "mrtx_get_config")
+        return {name: int(getattr(cfg, name)) for name, _ in MrtxConfig._fields_}
+
     # ---- multi-GPU exchange
+    def set_gather_hits(self, on):
+        """Whether the hit buffer travels with the radiance in pack / unpack (mrtx_set_gather_hits; alike on every rank)."""
+        self._check(self._lib.mrtx_set_gather_hits(self._ctx, 1 if on else 0), "mrtx_set_gather_hits")
+
     def shard_bytes(self, rank=None):
         n = C.c_uint64()
         self._check(self._lib.mrtx_shard_bytes(self._ctx, self.rank if rank is None else rank, C.byref(n)),

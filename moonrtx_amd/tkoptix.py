@@ -19,6 +19,7 @@ are None and the `_gui_*` handler slots are plain attributes a viewer may call. 
 max_accumulation_frames=64 is ONE launch, max_accumulation_frames=1 (the interactive preview,
 moon_renderer.py:457-488) is a 1-spp launch.  The NVENC encoder is refused explicitly (no AMD analogue here).
 """
+import os
 import threading
 import warnings
 
@@ -93,10 +94,13 @@ class _OptixShim:
 
 class TkOptiX:
     def __init__(self, width=-1, height=-1, on_launch_finished=None, on_rt_completed=None, start_now=False,
-                 device=0, backend=None, **_ignored):
+                 device=0, backend=None, progressive=False, **_ignored):
+        """`progressive` (this backend's own option, default off): honour `min_accumulation_step` launch by launch as PlotOptiX
+        does -- see set_param()."""
         if width <= 0 or height <= 0:
             raise ValueError("headless backend needs explicit width and height")
         self._width, self._height = int(width), int(height)
+        self._progressive = bool(progressive) or os.environ.get("MOONRT_PROGRESSIVE") == "1"
         if backend is None:
             from .renderer import MoonRT
             backend = MoonRT(self._width, self._height, device=device)
@@ -145,7 +149,17 @@ class TkOptiX:
 
     # ------------------------------------------------------------------ parameters
     def set_param(self, **kwargs):
-        """set_param(min_accumulation_step=, max_accumulation_frames=) -- moon_renderer.py:578, :475, :487."""
+        """set_param(min_accumulation_step=, max_accumulation_frames=) -- moon_renderer.py:578, :475, :487.
+
+        DEVIATION FROM PLOTOPTIX, on purpose: the reference asks for `min_accumulation_step=1, max_accumulation_frames=64`, i.e.
+        64 launches of one frame each and one `on_launch_finished` per launch (its status line counts them,
+        renderer_status.py:239).  This backend renders a cycle of n frames as ONE launch of n samples per pixel (n <= 64; beyond
+        that, n / 64 launches of 64) and calls `on_launch_finished` once per launch -- once per 64-frame cycle: a converged 4K
+        image takes 22 ms that way, so there is nothing for a progress display to show, and 64 separate launches + image
+        read-backs would cost ~5x as much (bench.py's `facade` entry times both).  `min_accumulation_step` is stored and
+        otherwise ignored.  Opt in to PlotOptiX's launch-by-launch behaviour with TkOptiX(..., progressive=True) or
+        MOONRT_PROGRESSIVE=1: every launch then adds `min_accumulation_step` frames (rounded down to a power of two <= 64) and
+        fires its own callback; the converged image is the same bits either way (the samples are keyed by their index)."""
         with self._padlock:
             for k, v in kwargs.items():
                 if k not in ("min_accumulation_step", "max_accumulation_frames", "light_shading", "compute_timeout",
@@ -401,8 +415,11 @@ class TkOptiX:
     # ------------------------------------------------------------------ render loop
     def _cycle_plan(self):
         n = max(1, int(self._params["max_accumulation_frames"]))
+        cap = min(n, 64)
+        if self._progressive:               # PlotOptiX's way: min_accumulation_step frames per launch (see set_param)
+            cap = min(cap, max(1, int(self._params["min_accumulation_step"])))
         s = 1
-        while s * 2 <= min(n, 64):
+        while s * 2 <= cap:
             s *= 2
         return s, max(1, n // s)            # samples per launch, launches per cycle
 
@@ -474,12 +491,16 @@ class TkOptiX:
             self._wake.notify_all()
 
     def render_cycle(self):
-        """Headless helper: run one full accumulation cycle synchronously on the calling thread."""
+        """Headless helper: run one full accumulation cycle synchronously on the calling thread; `on_launch_finished` fires after
+        every launch, as on the render thread."""
         with self._padlock:
             self._dirty = True
-            while not self._launch_once():
-                pass
-            return self._image
+            while True:
+                done = self._launch_once()
+                if self._on_launch_finished is not None:
+                    self._on_launch_finished(self)
+                if done:
+                    return self._image
 
     def set_accum_done_cb(self, cb):
         """set_accum_done_cb(cb_or_None) -- renderer_video.py:260, :322."""
@@ -532,7 +553,11 @@ class TkOptiX:
         bps = getattr(bps, "name", bps)
         with self._padlock:
             if str(bps) == "Bps16":
-                self._push_params(self._cycle_plan()[0])      # exposure / gamma as they stand now
+                # exposure / gamma as they stand now -- and ONLY those: pushing the cycle plan here as well would try to change
+                # spp_per_launch inside an accumulation cycle after set_param(max_accumulation_frames=...) (MRTX_E_STATE)
+                tone = {k: self._floats[k] for k in ("tonemap_exposure", "tonemap_gamma") if k in self._floats}
+                if tone:
+                    self._rt.set_params(**tone)
                 arr = self._rt.read_rgb16()                   # exact 16-bit "Gamma" post-process on the device
                 ext = str(file_name).lower().rsplit(".", 1)[-1]
                 if ext in ("tif", "tiff"):

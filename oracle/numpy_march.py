@@ -19,8 +19,9 @@ def _dem_bilinear(dem, lat, lon):
     c0 = np.floor(col).astype(np.int64) % w
     c1 = (c0 + 1) % w
     fc = col - np.floor(col)
-    return (dem[r0, c0] * (1 - fr) * (1 - fc) + dem[r0 + 1, c0] * fr * (1 - fc)
-            + dem[r0, c1] * (1 - fr) * fc + dem[r0 + 1, c1] * fr * fc)
+    f64 = np.float64
+    return (dem[r0, c0].astype(f64) * (1 - fr) * (1 - fc) + dem[r0 + 1, c0].astype(f64) * fr * (1 - fc)
+            + dem[r0, c1].astype(f64) * (1 - fr) * fc + dem[r0 + 1, c1].astype(f64) * fr * fc)
 
 
 def _height(dem, p):
@@ -64,15 +65,22 @@ def _duff_basis(n):
     return b1, b2
 
 
-def render(scene, dem, spp, seed=1234, albedo=None, spec_rng=False):
+def render(scene, dem, spp, seed=1234, albedo=None, spec_rng=False, region=None, counts=None):
     """Mean linear radiance (H, W, 3) with `spp` jittered samples per pixel.
+
+    `region` = (x0, y0, x1, y1): only these pixels of the frame (the result has their shape) -- bench.py's numpy CPU baseline
+    times row bands of a crop in parallel processes.  `counts`: a dict that receives "rays" and "dem_samples" (bilinear DEM
+    evaluations performed).  The DEM is used as it comes (float32 stays float32 in memory: a cfg3 DEM is 4.25 GB; every fetched
+    value is widened to float64 for the arithmetic, which is what converting the whole array first did).
 
     spec_rng=False: own RNG (statistical check).  spec_rng=True: the spec's uniforms for (pixel, sample) and its light-cone
     parameterisation (Duff basis), still in float64 with library trig and exact evaluation at every step -- the SAME rays up
     to rounding, so the comparison with the oracle becomes per pixel: only samples that sit on a hit / shadow decision
     boundary may differ."""
-    dem = np.asarray(dem, np.float64)
+    dem = np.asarray(dem)
+    n_dem = [0]
     W, H, R = scene.width, scene.height, float(scene.radius)
+    x0, y0, x1, y1 = region if region is not None else (0, 0, W, H)
     rng = np.random.default_rng(seed)
     eye, tgt, up = (np.asarray(v, float) for v in (scene.eye, scene.target, scene.up))
     wv = tgt - eye; wv /= np.linalg.norm(wv)
@@ -86,13 +94,13 @@ def render(scene, dem, spp, seed=1234, albedo=None, spec_rng=False):
     Lb = M @ (np.asarray(scene.light_pos, float) - centre)
     alb = np.asarray(scene.const_albedo if albedo is None else albedo, float)
     step, eps, seps = scene.marching_step, scene.marching_step_eps, scene.scene_epsilon
-    out = np.zeros((H, W, 3))
-    ys, xs = np.mgrid[0:H, 0:W]
+    out = np.zeros((y1 - y0, x1 - x0, 3))
+    ys, xs = np.mgrid[y0:y1, x0:x1]
     for gs in range(spp):
         if spec_rng:
-            u0, u1, u2, u3 = spec_uniforms(scene, gs)
+            u0, u1, u2, u3 = (u[y0:y1, x0:x1] for u in spec_uniforms(scene, gs))
         else:
-            u0, u1, u2, u3 = (rng.random((H, W)) for _ in range(4))
+            u0, u1, u2, u3 = (rng.random((y1 - y0, x1 - x0)) for _ in range(4))
         fx = xs + u0; fy = ys + u1
         sx = (fx / W * 2 - 1) * th * W / H; sy = (1 - fy / H * 2) * th
         d = wv + sx[..., None] * uv + sy[..., None] * vv
@@ -120,7 +128,7 @@ def render(scene, dem, spp, seed=1234, albedo=None, spec_rng=False):
             a = np.flatnonzero(active)
             if a.size == 0:
                 break
-            bel = _below(dem, R, pe[a] + s * dd[a])
+            bel = _below(dem, R, pe[a] + s * dd[a]); n_dem[0] += a.size
             h_ = a[bel]
             hit[h_] = True; hi[h_] = s; lo[h_] = (k - 1) * step
             active[h_] = False
@@ -131,7 +139,7 @@ def render(scene, dem, spp, seed=1234, albedo=None, spec_rng=False):
         width = step
         while width > eps:
             mid = 0.5 * (lo[hh] + hi[hh])
-            bel = _below(dem, R, pe[hh] + mid[:, None] * dd[hh])
+            bel = _below(dem, R, pe[hh] + mid[:, None] * dd[hh]); n_dem[0] += hh.size
             hi[hh] = np.where(bel, mid, hi[hh]); lo[hh] = np.where(bel, lo[hh], mid)
             width *= 0.5
         p = pe[hh] + lo[hh][:, None] * dd[hh]
@@ -143,6 +151,7 @@ def render(scene, dem, spp, seed=1234, albedo=None, spec_rng=False):
         dlat = (_dem_bilinear(dem, np.clip(lat + dla, -np.pi / 2, np.pi / 2), lon)
                 - _dem_bilinear(dem, np.clip(lat - dla, -np.pi / 2, np.pi / 2), lon)) / (2 * dla)
         dlon = (_dem_bilinear(dem, lat, lon + dlo) - _dem_bilinear(dem, lat, lon - dlo)) / (2 * dlo)
+        n_dem[0] += 4 * hh.size
         rhat = p / r[:, None]
         sphi, cphi, slam, clam = p[:, 2] / r, rho / r, p[:, 0] / rho, p[:, 1] / rho
         north = np.stack([-sphi * slam, -sphi * clam, cphi], -1)
@@ -175,9 +184,12 @@ def render(scene, dem, spp, seed=1234, albedo=None, spec_rng=False):
             act[a[outside]] = False
             a = a[~outside]
             if a.size:
-                bel = _below(dem, R, o[a] + (k * step) * wi[a])
+                bel = _below(dem, R, o[a] + (k * step) * wi[a]); n_dem[0] += a.size
                 lit[a[bel]] = False; act[a[bel]] = False
             k += 1
         wgt = np.where(lit, 2 * scene.light_radiance * omc * cosi, 0.0)
         np.add.at(out, (pix[:, 0], pix[:, 1]), wgt[:, None] * alb[None, :])
+    if counts is not None:
+        counts["rays"] = counts.get("rays", 0) + (y1 - y0) * (x1 - x0) * spp
+        counts["dem_samples"] = counts.get("dem_samples", 0) + n_dem[0]
     return out / spp

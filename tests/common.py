@@ -4,7 +4,8 @@ import numpy as np
 from oracle import orc
 from moonrtx_amd.renderer import MoonRT
 
-EXTRA_KEYS = ("dem_fetches", "mip_fetches", "kernel_ms", "primary_ms", "paths_ms", "launches")
+EXTRA_KEYS = ("dem_fetches", "mip_fetches", "kernel_ms", "primary_ms", "paths_ms", "launches",
+              "camera_height_samples", "camera_dem_fetches", "camera_mip_fetches", "camera_colour_fetches", "camera_background_fetches")
 STAT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "colour_fetches",
              "background_fetches", "bounce_rays", "bounce_sun_hits")
 

@@ -197,9 +197,12 @@ class InputGuard:
                 av = np.ascontiguousarray(a).view(np.uint8).ravel(); bv = b.view(np.uint8).ravel()
                 bad = np.flatnonzero(av != bv) if av.size == bv.size else np.array([0])
                 o = int(bad[0]) & ~3
+                words = sorted({int(t) & ~7 for t in bad})[:8]
+                detail = "; ".join(f"+{w}: {bytes(bv[w:w + 8]).hex()} -> {bytes(av[w:w + 8]).hex()}" for w in words)
                 raise InputChanged(f"{self.desc}: the {k} array CHANGED UNDER THE TEST ({when}): {len(bad)} byte(s) differ, first at byte "
                                    f"offset {int(bad[0])}; word at {o}: {bytes(bv[o:o + 4]).hex()} -> {bytes(av[o:o + 4]).hex()} "
-                                   "(not a parity failure: the two sides were given different inputs)")
+                                   f"(not a parity failure: the two sides were given different inputs) [{av.size}-byte array at "
+                                   f"0x{np.ascontiguousarray(a).ctypes.data:x}; 8-byte words that differ: {detail}]")
 
 
 def check_case(c):

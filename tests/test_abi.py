@@ -25,10 +25,10 @@ def test_every_declared_symbol_is_exported_and_bound(native_lib):
 
 def test_abi_version_and_struct_layouts(native_lib):
     from moonrtx_amd import _lib
-    assert native_lib.mrtx_abi_version() == 6
+    assert native_lib.mrtx_abi_version() == 7
     assert C.sizeof(_lib.MrtxConfig) == 28
     assert C.sizeof(_lib.MrtxParams) == 56
-    assert C.sizeof(_lib.MrtxStats) == 112
+    assert C.sizeof(_lib.MrtxStats) == 152
     p = _lib.MrtxParams()
     native_lib.mrtx_default_params(C.byref(p))
     # moon_renderer.py:99-101, :583, :598, :130

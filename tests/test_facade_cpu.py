@@ -262,3 +262,57 @@ def test_save_image_16_bits_is_really_16_bits(tmp_path):
     with pytest.raises(ValueError):
         rt.save_image(str(tmp_path / "frame.jpg"), bps="Bps16")
     rt.close()
+
+
+def test_one_callback_per_cycle_by_default_and_per_frame_when_progressive():
+    """The documented deviation at the boundary (set_param's docstring): the reference's
+    `min_accumulation_step=1, max_accumulation_frames=64` (moon_renderer.py:578) is ONE launch of 64 samples and ONE
+    on_launch_finished here; TkOptiX(progressive=True) gives PlotOptiX's 64 launches of one frame (renderer_status.py:239)."""
+    for progressive, launches, spp in ((False, 1, 64), (True, 64, 1)):
+        be = RecordingBackend(16, 8)
+        fired = []
+        rt = TkOptiX(width=16, height=8, on_launch_finished=lambda r: fired.append(1), backend=be, progressive=progressive)
+        drive_like_init_renderer(rt, np.ones((4, 8), np.float32), np.zeros((4, 8, 4), np.uint8))
+        rt.render_cycle()
+        renders = [c for c in be.calls if c[0] == "render"]
+        assert len(renders) == launches and len(fired) == launches, (progressive, len(renders), len(fired))
+        assert be.last("set_params")[2]["spp_per_launch"] == spp and be.last("set_params")[2]["max_spp"] == 64
+        rt.set_param(min_accumulation_step=8)           # progressive: 8 launches of 8 frames; default: still one launch
+        be.calls.clear(); fired.clear()
+        rt.render_cycle()
+        assert len([c for c in be.calls if c[0] == "render"]) == (8 if progressive else 1) == len(fired)
+        rt.close()
+
+
+def test_save_image_16_bits_after_changing_the_cycle_length(tmp_path):
+    """render_cycle -> set_param(max_accumulation_frames=...) -> save_image(Bps16) (the headless export sequence): the save pushes
+    exposure and gamma only -- re-pushing the cycle plan would ask the library to change spp_per_launch inside an accumulation
+    cycle (MRTX_E_STATE; round-3 advisor finding)."""
+    class Backend(RecordingBackend):
+        def __getattr__(self, name):
+            inner = RecordingBackend.__getattr__(self, name)
+
+            def rec(*a, **k):
+                if name == "set_params" and "spp_per_launch" in k and self.blocks and k["spp_per_launch"] != self.spp:
+                    raise RuntimeError("spp_per_launch cannot change inside an accumulation cycle; reset first")
+                if name == "set_params" and "spp_per_launch" in k:
+                    self.spp = k["spp_per_launch"]
+                if name == "read_rgb16":
+                    self.calls.append((name, a, k))
+                    return np.full((self.height, self.width, 3), 4660, np.uint16)
+                return inner(*a, **k)
+            return rec
+
+    be = Backend(16, 8)
+    be.spp = None
+    rt = TkOptiX(width=16, height=8, backend=be)
+    drive_like_init_renderer(rt, np.ones((4, 8), np.float32), np.zeros((4, 8, 4), np.uint8))
+    rt.render_cycle()                                   # 64 samples accumulated
+    rt.set_param(max_accumulation_frames=1)             # the preview setting, no new cycle rendered yet
+    rt.set_float("tonemap_gamma", 1.8)
+    out = tmp_path / "frame.tiff"
+    rt.save_image(str(out), bps="Bps16")
+    assert out.stat().st_size > 16 * 8 * 6
+    pushed = be.last("set_params")[2]
+    assert pushed == {"tonemap_exposure": 0.9, "tonemap_gamma": 1.8}
+    rt.close()

@@ -104,10 +104,14 @@ def test_cfg2_full_size(cfg2_inputs, name, seg):
 
 
 def test_cfg4_one_rank_of_eight_at_full_size(native_lib):
-    """7680x4320, 256 spp (4 blocks of 64), the full-resolution DEM: rank 3 of 8 renders its tile lattice."""
+    """7680x4320, 256 spp (4 blocks of 64), the full-resolution DEM, the colour map of cfg 3 ("colour as cfg 3"):
+    rank 3 of 8 renders its tile lattice; the root (rank 0) renders its own and takes rank 3's shard in."""
     W, H, S, DH, DW, RANK, WORLD = 7680, 4320, 64, 46080, 92160, 3, 8
+    CH, CW = 13680, 27360
     dem_b, scale = device_dem(DH, DW)
     assert 1.005 < scale < 1.0075
+    from moonrtx_amd.renderer import synth_color, DeviceBuffer
+    col_b = synth_color(CH, CW)
     s = named_scene("S1", W, H, spp_per_launch=S)
     s.max_spp = 256
 
@@ -115,6 +119,7 @@ def test_cfg4_one_rank_of_eight_at_full_size(native_lib):
         s.path_seg_min, s.path_seg_max = seg
         rt = MoonRT(W, H, rank=RANK, world=WORLD)
         rt.bind_dem(dem_b, DH, DW)
+        rt.bind_color(col_b, CH, CW)
         rt.apply_scene(s); rt.set_params(flags=flags)
         st = rt.render(blocks)
         out = rt.read_linear(), rt.read_hits(), st
@@ -147,19 +152,40 @@ def test_cfg4_one_rank_of_eight_at_full_size(native_lib):
     b, hb, _ = render((2, 4), _lib.F_INWAVE_PATHS, blocks=1)
     assert_bit_equal(a, b, "cfg4 shard: path queue vs in-wave radiance")
     assert sta["paths_ms"] > 0
+    # the ROOT of the eight: rank 0 renders its own lattice (one block, (2, 4)), rank 3 packs what it rendered above (hit-less: the
+    # final linear framebuffer is what the exchange moves) and the root unpacks it beside its own tiles
+    r3 = MoonRT(W, H, rank=RANK, world=WORLD); r3.set_gather_hits(False)
+    r3.bind_dem(dem_b, DH, DW); r3.bind_color(col_b, CH, CW); r3.apply_scene(s); r3.set_params(flags=0); r3.render(1)
+    r0 = MoonRT(W, H, rank=0, world=WORLD); r0.set_gather_hits(False)
+    r0.bind_dem(dem_b, DH, DW); r0.bind_color(col_b, CH, CW); r0.apply_scene(s); r0.set_params(flags=0); r0.render(1)
+    assert r0.shard_bytes_active() == r3.shard_bytes_active() < r0.shard_bytes() == (W // 32) * (H // 32) // WORLD * 32 * 32 * 16
+    buf = DeviceBuffer(r3.shard_bytes())
+    r3.pack_shard(buf.ptr)
+    own0 = np.kron((tid % WORLD == 0).reshape(-1, tiles_x), np.ones((32, 32), bool))[:H, :W]
+    root_own = r0.read_linear()
+    assert root_own[~own0].max() == 0.0
+    r0.unpack_shard(RANK, buf.ptr)
+    root = r0.read_linear()
+    assert_bit_equal(root[own_px], a[own_px], "cfg4: rank 3's tiles on the root after the exchange")
+    assert_bit_equal(root[own0], root_own[own0], "cfg4: the root's own tiles untouched by the unpack")
+    assert root[~(own_px | own0)].max() == 0.0
+    r0.close(); r3.close(); buf.free()
     # one oracle crop: an owned tile on the terminator side of the disc, first block of 64 spp, direct light
     dem = dem_b.download(np.float32, (DH, DW))
     dem_b.free()
+    col = col_b.download(np.uint8, (CH, CW, 4))
+    col_b.free()
     s.path_seg_min, s.path_seg_max = 1, 1
     cand = [(x, y) for y in range(60, 75) for x in range(90, 150) if own[y, x]]
     tx0, ty0 = cand[len(cand) // 2]
     rt = MoonRT(W, H, rank=RANK, world=WORLD)
     rt.upload_dem(dem)                                   # the host-upload path at 17 GB as well
+    rt.upload_color(col)
     rt.apply_scene(s); rt.set_params(flags=0)
     rt.render(1)
     lin1, hits1 = rt.read_linear(), rt.read_hits()
     rt.close()
-    oracle_crops(s, dem, lin1, hits1, [(tx0 * 32, ty0 * 32, 32, 32)])
+    oracle_crops(s, dem, lin1, hits1, [(tx0 * 32, ty0 * 32, 32, 32)], col=col)
     # ... and the same owned tile of the (2, 4) frame rendered above through the path queue (first block of 64 spp)
     s.path_seg_min, s.path_seg_max = 2, 4
-    oracle_crops(s, dem, a, ha, [(tx0 * 32, ty0 * 32, 32, 32)])
+    oracle_crops(s, dem, a, ha, [(tx0 * 32, ty0 * 32, 32, 32)], col=col)

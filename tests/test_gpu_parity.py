@@ -425,6 +425,55 @@ def test_gather_moves_only_active_tiles_and_clears_stale_ones(native_lib, dem_sm
             rt.close()
 
 
+def test_hitless_exchange_config_and_stage_counters(native_lib, dem_small):
+    """ABI 7: mrtx_set_gather_hits(0) halves the shard (the final linear framebuffer is all that travels) and leaves the root's
+    hit buffer to its own tiles, one texel of a peer's tile coming from mrtx_read_hit on that peer; mrtx_get_config reports the
+    tiling in force; MrtxStats::camera_* split the counters between render_kernel and path_kernel."""
+    from moonrtx_amd.renderer import MoonRT, DeviceBuffer
+    from moonrtx_amd import _lib, dist as mdist
+    s = named_scene("S1", 100, 70, spp_per_launch=4)
+    s.path_seg_min, s.path_seg_max = 2, 4
+    lin_1, hits_1, st_1, _ = render_hip(s, dem_small, tile=(16, 16))
+    # stage counters: with the queue the camera stage holds part of every total, in the wave all of it
+    for k in ("height_samples", "dem_fetches", "mip_fetches", "colour_fetches", "background_fetches"):
+        assert 0 < st_1["camera_" + k] <= st_1[k] if st_1[k] else st_1["camera_" + k] == 0, (k, st_1)
+    assert st_1["camera_dem_fetches"] < st_1["dem_fetches"] and st_1["camera_height_samples"] < st_1["height_samples"]
+    _, _, st_w, _ = render_hip(s, dem_small, tile=(16, 16), flags=_lib.F_COUNT_STATS | _lib.F_INWAVE_PATHS)
+    assert all(st_w["camera_" + k] == st_w[k] == st_1[k] for k in ("height_samples", "dem_fetches", "colour_fetches"))
+    d = MoonRT(64, 48); cfg1 = d.config(); d.close()
+    d = MoonRT(64, 48, rank=1, world=4); cfg4 = d.config(); d.close()
+    assert (cfg1["tile_w"], cfg1["tile_h"], cfg1["world"]) == (16, 16, 1) and (cfg4["tile_w"], cfg4["tile_h"], cfg4["rank"], cfg4["world"]) == (32, 32, 1, 4)
+    for world in (2, 3):
+        rts = []
+        for r in range(world):
+            rt = MoonRT(s.width, s.height, rank=r, world=world, tile=(16, 16))
+            full = rt.shard_bytes()
+            rt.set_gather_hits(False)
+            assert rt.shard_bytes() * 2 == full
+            rt.upload_dem(dem_small); rt.apply_scene(s); rt.render(1)
+            rts.append(rt)
+        assert rts[0].shard_bytes_active() < rts[0].shard_bytes()
+        bufs = [DeviceBuffer(rt.shard_bytes()) for rt in rts]
+        for rt, b in zip(rts, bufs):
+            rt.pack_shard(b.ptr)
+        rts[0].unpack_all([b.ptr for b in bufs])
+        assert_bit_equal(rts[0].read_linear(), lin_1, f"world={world} radiance through the hit-less exchange")
+        own = np.zeros((s.height, s.width), bool)
+        for y in range(0, s.height, 16):
+            for x in range(0, s.width, 16):
+                own[y:y + 16, x:x + 16] = mdist.tile_owner(x, y, s.width, (16, 16), world) == 0
+        got = rts[0].read_hits()
+        assert np.array_equal(got[own].view(np.uint32), hits_1[own].view(np.uint32)) and not got[~own].any()
+        for (x, y) in ((50, 35), (20, 30), (70, 40), (45, 20)):          # a pick: the owner's one texel
+            o = mdist.tile_owner(x, y, s.width, (16, 16), world)
+            assert np.array_equal(np.array(rts[o].read_hit(x, y), np.float32).view(np.uint32), hits_1[y, x].view(np.uint32)), (x, y, o)
+        assert hits_1[35, 50, 3] > 0
+        for rt in rts:
+            rt.close()
+        for b in bufs:
+            b.free()
+
+
 _RCCL_SNIPPET = r"""
 import os, sys, tempfile, torch, torch.distributed as dist
 with tempfile.TemporaryDirectory() as d:
@@ -604,7 +653,7 @@ def test_render_and_gather_async_branch_with_a_stand_in_collective(native_lib, d
         from moonrtx_amd.renderer import MoonRT
         from moonrtx_amd.scene import named_scene
 
-        world = int(sys.argv[1])
+        world = int(sys.argv[1]); with_hits = sys.argv[2] == "1"
         lock = threading.Lock()
         calls = {}                                   # call index -> {"bar": Barrier, "src": {rank: tensor}, "dst": list}
         counters = [0] * world
@@ -643,8 +692,9 @@ def test_render_and_gather_async_branch_with_a_stand_in_collective(native_lib, d
                 tls.rank = rank
                 rt = MoonRT(scene.width, scene.height, rank=rank, world=world, tile=(16, 16))
                 rt.upload_dem(dem); rt.apply_scene(scene)
-                g = mdist.FrameGather(rt, torch.device("cuda", 0))
+                g = mdist.FrameGather(rt, torch.device("cuda", 0), with_hits=with_hits)
                 assert rt.shard_parts(2) == 2
+                assert rt.shard_bytes() == rt.config()["tile_w"] * rt.config()["tile_h"] * (32 if with_hits else 16) * -(-(12 * 6) // world)
                 for _ in range(2):                   # twice: buffers and counters are reused
                     rt.reset()
                     st = g.render_and_gather(1, parts=2)
@@ -658,9 +708,17 @@ def test_render_and_gather_async_branch_with_a_stand_in_collective(native_lib, d
         [t.start() for t in th]; [t.join(120) for t in th]
         assert not errs, errs
         assert np.array_equal(out["lin"].view(np.uint32), want.view(np.uint32)), "radiance"
-        assert np.array_equal(out["hits"].view(np.uint32), want_h.view(np.uint32)), "hits"
+        if with_hits:
+            assert np.array_equal(out["hits"].view(np.uint32), want_h.view(np.uint32)), "hits"
+        else:       # the final linear framebuffer is what travelled: the root's hit buffer holds its own tiles, nothing else
+            own = np.zeros((scene.height, scene.width), bool)
+            for y in range(0, scene.height, 16):
+                for x in range(0, scene.width, 16):
+                    own[y:y + 16, x:x + 16] = mdist.tile_owner(x, y, scene.width, (16, 16), world) == 0
+            assert np.array_equal(out["hits"][own].view(np.uint32), want_h[own].view(np.uint32)), "own hits"
+            assert not out["hits"][~own].any(), "peer hits must not have travelled"
         print("ok", world, len(calls))
     """)
-    for world in (2, 3):
-        r = subprocess.run([sys.executable, "-c", code, str(world)], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+    for world, with_hits in ((2, 0), (3, 1), (4, 0), (8, 0), (8, 1)):
+        r = subprocess.run([sys.executable, "-c", code, str(world), str(with_hits)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (world, with_hits, r.stdout[-500:], r.stderr[-2500:])

@@ -182,7 +182,7 @@ def test_no_memory_for_the_records_falls_back_to_in_wave_paths(native_lib, rough
     lin_o2, hits_o2, st_o2 = render_oracle(s, rough, blocks=(1, 1))
     assert_bit_equal(lin, lin_o2, "fallback radiance"); assert_bit_equal(hits, hits_o2, "fallback hits")
     assert st["launches"] == 2 and st["paths_ms"] == 0.0
-    assert capfd.readouterr().err.count("keeps its paths inside the render wave") == 1      # said once per context
+    assert capfd.readouterr().err.count("keep their paths inside the render wave") == 1      # said once per context
 
 
 def test_path_stage_launch_parameters_are_validated(native_lib, rough, monkeypatch):
