@@ -68,6 +68,13 @@ struct mrtx_ctx {
     // 2.41, 4 spp 3.42 / 3.16; cfg1 0.33 / 0.53; tools/spp_sweep.py).  MOONRT_PATH_QUEUE_MIN overrides (0 = always the queue).
     uint64_t path_queue_min = 8000000ull;
     bool path_fallback_said = false;     // the fall-back to in-wave paths (no memory for the records) was reported
+    // overlapped path stage (MOONRT_PATH_OVERLAP = sub-parts, 0 = off): path_kernel + resolve of sub-part i run on stream2 beside
+    // render_kernel of sub-part i+1 (two sets of hand-over buffers, ping-pong); MOONRT_PATH_OVERLAP_WAVES sizes the persistent
+    // launch while it shares the chip (every path wave holds 96 VGPRs, a render wave 64)
+    int path_overlap = 0, path_overlap_waves = 2048;
+    int path_sets = 1;                   // buffer sets the allocations hold
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ov_done[2] = {nullptr, nullptr}, ov_join = nullptr;
     uint64_t path_nomem_chunks = 0;      // a hand-over allocation of this many chunks failed: not retried until less is needed or mrtx_reset_accum
     bool gather_hits = true;             // mrtx_set_gather_hits: the hit buffer travels with the radiance
     bool path_alloc_fail_test = false;   // MOONRT_TEST_PATH_NOMEM=1: test hook, the hand-over allocation "fails"
@@ -541,6 +548,8 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
         if ((e = std::getenv("MOONRT_PATH_WAVES")) && std::atoi(e) >= 8 * c->path_nsub) c->path_waves_env = std::atoi(e) / 8 * 8;   // every work counter needs a consumer (read after MOONRT_PATH_NSUB)
         if ((e = std::getenv("MOONRT_PATH_QUEUE_MIN")) && std::atof(e) >= 0.0) c->path_queue_min = (uint64_t)std::atof(e);
         if ((e = std::getenv("MOONRT_TEST_PATH_NOMEM")) && std::atoi(e) == 1) c->path_alloc_fail_test = true;
+        if ((e = std::getenv("MOONRT_PATH_OVERLAP")) && std::atoi(e) >= 0 && std::atoi(e) <= 64) c->path_overlap = std::atoi(e) == 1 ? 0 : std::atoi(e);
+        if ((e = std::getenv("MOONRT_PATH_OVERLAP_WAVES")) && std::atoi(e) >= 8 * c->path_nsub) c->path_overlap_waves = std::atoi(e) / 8 * 8;
     }
     c->tiles_x = (cfg->width + c->cfg.tile_w - 1) / c->cfg.tile_w;
     c->tiles_y = (cfg->height + c->cfg.tile_h - 1) / c->cfg.tile_h;
@@ -596,6 +605,8 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->color) (void)hipFree(c->color);
     if (c->bg) (void)hipFree(c->bg);
     if (c->overlay) (void)hipFree(c->overlay);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); put_stream(c->cfg.device, c->stream2); }
+    put_event(c->cfg.device, c->ov_done[0]); put_event(c->cfg.device, c->ov_done[1]); put_event(c->cfg.device, c->ov_join);
     put_event(c->cfg.device, c->ev0);
     put_event(c->cfg.device, c->ev1);
     put_stream(c->cfg.device, c->stream);      // synchronised above
@@ -915,6 +926,7 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     std::vector<FrameC> fs;
     std::vector<PathQ> pqs;
     int n_sub = 1;
+    bool overlap = false;                // path stage of sub-part i beside the render kernel of sub-part i + 1 (MOONRT_PATH_OVERLAP)
     auto fall_back = [&](const char* why) {
         if (!c->path_fallback_said) {
             std::fprintf(stderr, "libmoonrt: %s -- frames of this size keep their paths inside the render wave (same result, slower); "
@@ -935,6 +947,9 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         const uint64_t full = mrtx_path_chunks(f, S, nullptr, nullptr);
         if (full > cap_chunks && f.tile_list != nullptr) n_sub = (int)std::min<uint64_t>((uint64_t)f.n_active, (full + cap_chunks - 1) / cap_chunks);
     }
+    overlap = c->path_overlap > 1 && f.tile_list != nullptr && f.n_active >= 8 * c->path_overlap && !stats;
+    if (overlap) n_sub = std::max(n_sub, c->path_overlap);
+    const int sets = overlap ? 2 : 1;
     fs.assign((size_t)n_sub, f);
     pqs.assign((size_t)n_sub, PathQ());
     uint64_t chunks = 0;
@@ -949,15 +964,15 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         fall_back("the frame holds more wave-jobs than one deferred-path launch can index");
     } else if (chunks > c->path_cap && c->path_nomem_chunks != 0 && chunks >= c->path_nomem_chunks) {
         mode = 1;      // an allocation of this size failed before: do not free and retry three multi-gigabyte hipMallocs per frame
-    } else if (chunks > c->path_cap) {
+    } else if (chunks > c->path_cap || sets > c->path_sets) {
         if (c->path_rec) { HIPCHK(c, hipFree(c->path_rec)); c->path_rec = nullptr; }
         if (c->path_meta) { HIPCHK(c, hipFree(c->path_meta)); c->path_meta = nullptr; }
         if (c->path_npaths) { HIPCHK(c, hipFree(c->path_npaths)); c->path_npaths = nullptr; }
         c->path_cap = 0;
         if (c->path_alloc_fail_test ||
-            hipMalloc((void**)&c->path_rec, (size_t)chunks * 64 * MRTX_PATH_REC_BYTES) != hipSuccess ||
-            hipMalloc((void**)&c->path_meta, (size_t)chunks * sizeof(uint32_t)) != hipSuccess ||
-            hipMalloc((void**)&c->path_npaths, (size_t)chunks + 64) != hipSuccess) {
+            hipMalloc((void**)&c->path_rec, (size_t)sets * (size_t)chunks * 64 * MRTX_PATH_REC_BYTES) != hipSuccess ||
+            hipMalloc((void**)&c->path_meta, (size_t)sets * (size_t)chunks * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&c->path_npaths, (size_t)sets * ((size_t)chunks + 64)) != hipSuccess) {
             (void)hipGetLastError();                                    // clear the allocation error: the frame is still rendered
             if (c->path_rec) { (void)hipFree(c->path_rec); c->path_rec = nullptr; }
             if (c->path_meta) { (void)hipFree(c->path_meta); c->path_meta = nullptr; }
@@ -966,14 +981,16 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             fall_back("no device memory for the hand-over records");
         } else {
             c->path_cap = chunks;
+            c->path_sets = sets;
             c->path_nomem_chunks = 0;
         }
     }
     const size_t n = (size_t)c->path_cap * 64;
-    if (mode == 2 && !c->path_ctr) HIPCHK(c, hipMalloc((void**)&c->path_ctr, 8 * 16 * sizeof(uint32_t)));
+    if (mode == 2 && !c->path_ctr) HIPCHK(c, hipMalloc((void**)&c->path_ctr, 2 * 8 * 16 * sizeof(uint32_t)));
     for (int s = 0; mode == 2 && s < n_sub; s++) {
         PathQ& pq = pqs[(size_t)s];
-        pq.ray0 = reinterpret_cast<float4*>(c->path_rec); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
+        const size_t set = overlap ? (size_t)(s & 1) : 0;     // ping-pong: sub-part s hands over through buffer set s % 2
+        pq.ray0 = reinterpret_cast<float4*>(reinterpret_cast<char*>(c->path_rec) + set * n * MRTX_PATH_REC_BYTES); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
 #if MRTX_C_AOS
         pq.c4 = pq.ray2 + n; pq.c0 = pq.c1 = pq.c2 = nullptr;
         pq.lane_of = reinterpret_cast<uint32_t*>(pq.c4 + n);
@@ -981,9 +998,9 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         pq.c0 = reinterpret_cast<float*>(pq.ray2 + n); pq.c1 = pq.c0 + n; pq.c2 = pq.c1 + n; pq.c4 = nullptr;
         pq.lane_of = reinterpret_cast<uint32_t*>(pq.c2 + n);
 #endif
-        pq.npaths = c->path_npaths;
-        pq.meta = c->path_meta;
-        pq.counters = c->path_ctr; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
+        pq.npaths = c->path_npaths + set * ((size_t)c->path_cap + 64);
+        pq.meta = c->path_meta + set * (size_t)c->path_cap;
+        pq.counters = c->path_ctr + set * 8 * 16; pq.n_sub = c->path_nsub; pq.grp_log2 = c->path_grp_log2;
         pq.n_chunks = (uint32_t)((uint64_t)pq.grid_a << pq.njobs_log2);
         pq.s_log2 = 0;
         while ((1 << pq.s_log2) < S) pq.s_log2++;
@@ -1020,6 +1037,12 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         const int nw = c->path_waves_env ? c->path_waves_env : c->path_waves[wi];
         const size_t n_ev = (size_t)n_blocks * (size_t)n_sub * 3;
         while (c->evs.size() < n_ev) { hipEvent_t e; HIPCHK(c, get_event(c->cfg.device, &e)); c->evs.push_back(e); }
+        if (overlap) {
+            if (!c->stream2) HIPCHK(c, get_stream(c->cfg.device, &c->stream2));
+            for (int i = 0; i < 2; i++) if (!c->ov_done[i]) HIPCHK(c, get_event(c->cfg.device, &c->ov_done[i]));
+            if (!c->ov_join) HIPCHK(c, get_event(c->cfg.device, &c->ov_join));
+        }
+        size_t ov_idx = 0;                 // sub-part launches so far in this call (overlap: which buffer set / which `done` event)
         for (int32_t b = 0; b < n_blocks && f.n_active > 0; b++) {
             for (int s = 0; s < n_sub; s++) {
                 hipEvent_t* ev = &c->evs[((size_t)b * (size_t)n_sub + (size_t)s) * 3];
@@ -1028,15 +1051,38 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
                 fb.n_blocks = 1;
                 PathQ& pq = pqs[(size_t)s];
                 pq.gs_base = fb.first_block * (uint32_t)S;
-                HIPCHK(c, hipMemsetAsync(c->path_meta, 0, (size_t)pq.n_chunks * sizeof(uint32_t), c->stream));
-                HIPCHK(c, hipMemsetAsync(c->path_npaths, 0, (size_t)pq.n_chunks, c->stream));
-                HIPCHK(c, hipMemsetAsync(c->path_ctr, 0, 8 * 16 * sizeof(uint32_t), c->stream));
+                if (overlap) {
+                    // render(i) on the context's stream, paths(i) + resolve(i) on stream2 beside render(i + 1); buffer set i % 2 is
+                    // free again when paths(i - 2) has finished
+                    const int set = s & 1;
+                    if (ov_idx >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ov_done[set], 0));
+                    HIPCHK(c, hipMemsetAsync(pq.meta, 0, (size_t)pq.n_chunks * sizeof(uint32_t), c->stream));
+                    HIPCHK(c, hipMemsetAsync(pq.npaths, 0, (size_t)pq.n_chunks, c->stream));
+                    HIPCHK(c, hipMemsetAsync(pq.counters, 0, 8 * 16 * sizeof(uint32_t), c->stream));
+                    HIPCHK(c, hipEventRecord(ev[0], c->stream));
+                    HIPCHK(c, mrtx_launch_render(fb, S, stats, 2, overlay, &pq, c->stream));
+                    HIPCHK(c, hipEventRecord(ev[1], c->stream));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream2, ev[1], 0));
+                    const bool last = (b == n_blocks - 1) && (s == n_sub - 1);
+                    HIPCHK(c, mrtx_launch_paths(fb, pq, S, stats, last ? nw : std::min(nw, c->path_overlap_waves), c->stream2));
+                    HIPCHK(c, hipEventRecord(c->ov_done[set], c->stream2));
+                    HIPCHK(c, hipEventRecord(ev[2], c->stream2));
+                    ov_idx++;
+                    continue;
+                }
+                HIPCHK(c, hipMemsetAsync(pq.meta, 0, (size_t)pq.n_chunks * sizeof(uint32_t), c->stream));
+                HIPCHK(c, hipMemsetAsync(pq.npaths, 0, (size_t)pq.n_chunks, c->stream));
+                HIPCHK(c, hipMemsetAsync(pq.counters, 0, 8 * 16 * sizeof(uint32_t), c->stream));
                 HIPCHK(c, hipEventRecord(ev[0], c->stream));
                 HIPCHK(c, mrtx_launch_render(fb, S, stats, 2, overlay, &pq, c->stream));
                 HIPCHK(c, hipEventRecord(ev[1], c->stream));
                 HIPCHK(c, mrtx_launch_paths(fb, pq, S, stats, nw, c->stream));
                 HIPCHK(c, hipEventRecord(ev[2], c->stream));
             }
+        }
+        if (overlap && ov_idx > 0) {       // the context's stream goes on (sky tiles, watchdog read-back) when stream2 has drained
+            HIPCHK(c, hipEventRecord(c->ov_join, c->stream2));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ov_join, 0));
         }
         if (have_sky) {   // nothing but the environment can be seen from these tiles: no paths, no records
             HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1064,7 +1110,16 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             HIPCHK(c, hipEventElapsedTime(&a, c->ev0, c->ev1));
             primary_ms += a;
         }
-        for (size_t i = 0; i < (f.n_active > 0 ? (size_t)n_blocks * (size_t)n_sub : 0); i++) {
+        const size_t n_launched = f.n_active > 0 ? (size_t)n_blocks * (size_t)n_sub : 0;
+        if (overlap && n_launched > 0) {
+            // the two stages run side by side: primary_ms = first render start .. last render end, paths_ms = what of the path
+            // stage is still running after that (the EXPOSED part)
+            float a = 0.0f, p = 0.0f;
+            HIPCHK(c, hipEventElapsedTime(&a, c->evs[0], c->evs[(n_launched - 1) * 3 + 1]));
+            HIPCHK(c, hipEventElapsedTime(&p, c->evs[(n_launched - 1) * 3 + 1], c->evs[(n_launched - 1) * 3 + 2]));
+            primary_ms += a; paths_ms += p;
+        }
+        for (size_t i = 0; !overlap && i < n_launched; i++) {
             float a = 0.0f, p = 0.0f;
             HIPCHK(c, hipEventElapsedTime(&a, c->evs[i * 3], c->evs[i * 3 + 1]));
             HIPCHK(c, hipEventElapsedTime(&p, c->evs[i * 3 + 1], c->evs[i * 3 + 2]));

@@ -31,8 +31,9 @@
 #define CF(f) ((const __attribute__((address_space(4))) FrameCold*)(f).cold)
 
 #ifndef MRTX_TRIAL_BATCH
-#define MRTX_TRIAL_BATCH 2     // steps fetched together in the trial segment
-#endif
+#define MRTX_TRIAL_BATCH 1     // steps fetched together in the trial segment.  Round 4 (8 waves per SIMD, VALU issue 0.65): 1 step
+#endif                         // 16.20 ms against 16.34 with 2 -- the 64 continuation rays are incoherent, a speculated second step is
+                               // mostly thrown away; the coherent marches keep MRTX_STEP_BATCH = 2 (1: 16.64 ms, 3: 16.68)
 #ifndef MRTX_TRIAL_SEGMENT
 #define MRTX_TRIAL_SEGMENT 1   // 0 = hand every continuation ray to path_kernel unmarched (A/B switch, see trace_sample)
 #endif
@@ -206,7 +207,13 @@ __device__ __forceinline__ float dem_march(const FrameC& f, float rowf, float co
     // row-pair layout: element (r, c) = (D[r][c], D[r+1][c]); elements (r0, c0) and (r0, c0+1) are adjacent, so the
     // whole 2x2 footprint is ONE 16-byte load -- half the gather instructions and L1 tag look-ups of two row loads
     Quad q;
-    if (CP == 1) {
+    if (CP == 2) {
+        // TIMING-ONLY A/B (results wrong; -DMRTX_PATH_CP=2): what would path_kernel gain from a DEM of half the bytes per texel
+        // (16-bit codes: round-3 verdict item 6)?  The same gather, 8 bytes from a buffer addressed at 4 bytes per element, so
+        // that a 128-byte line covers 32 columns x 2 rows: an upper bound on the traffic effect, without any decode cost.
+        const Pair h = *reinterpret_cast<const Pair*>(WIDE ? base + ((uint64_t)idx << 2) : base + (idx << 2));
+        q.a = h.x; q.b = h.y; q.c = h.x; q.d = h.y;
+    } else if (CP == 1) {
         const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(WIDE ? base + ((uint64_t)idx << 3) : base + (idx << 3)));
         q.a = v.x; q.b = v.y; q.c = v.z; q.d = v.w;
     } else if (WIDE) q = *reinterpret_cast<const Quad*>(base + ((uint64_t)idx << 3));

@@ -23,6 +23,7 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         rt.bind_color(col, col_shape[0], col_shape[1])
         rt.apply_scene(scene)
         rt.set_params(flags=int(os.environ.get("MRTX_FLAGS", "0")))
+        rt.set_gather_hits(os.environ.get("HITS", "0") == "1")       # the exchange moves the linear framebuffer only by default (round 4)
         rt.reset(); rt.render(1)
         t = []
         P = rt.shard_parts(int(os.environ.get("PARTS", "1"))) if world > 1 else 1     # PARTS=2: as FrameGather.render_and_gather drives it
