@@ -61,6 +61,7 @@ struct mrtx_ctx {
     uint32_t* path_ctr = nullptr;        // 8 x 16 work counters of path_kernel
     unsigned long long* wd_host = nullptr;   // pinned: path_kernel's watchdog word
     uint64_t path_budget_bytes = 24ull << 30;   // hand-over buffers: frames that need more are rendered in sub-parts (MOONRT_PATH_MAX_GB)
+    bool path_budget_env = false;               // the budget was given explicitly: take it as it is (else: at most half of the free memory)
     int path_nsub = 4, path_grp_log2 = 3;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet
     // launches with fewer samples than this keep their paths inside the render wave (same result, bit for bit): the three
@@ -544,7 +545,7 @@ int mrtx_create(const MrtxConfig* cfg, mrtx_ctx** out) {
         if ((e = std::getenv("MOONRT_PATH_HITMIN")) && std::atoi(e) >= -64 && std::atoi(e) <= 64) c->path_hitmin = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_NSUB")) && std::atoi(e) >= 1 && std::atoi(e) <= 16) c->path_nsub = std::atoi(e);
         if ((e = std::getenv("MOONRT_PATH_GRP")) && std::atoi(e) >= 0 && std::atoi(e) <= 5) c->path_grp_log2 = std::atoi(e);   // + njobs_log2 (<= 1) <= 6: 64 chunks per group
-        if ((e = std::getenv("MOONRT_PATH_MAX_GB")) && std::atof(e) > 0.0) c->path_budget_bytes = (uint64_t)(std::atof(e) * 1073741824.0);
+        if ((e = std::getenv("MOONRT_PATH_MAX_GB")) && std::atof(e) > 0.0) { c->path_budget_bytes = (uint64_t)(std::atof(e) * 1073741824.0); c->path_budget_env = true; }
         if ((e = std::getenv("MOONRT_PATH_WAVES")) && std::atoi(e) >= 8 * c->path_nsub) c->path_waves_env = std::atoi(e) / 8 * 8;   // every work counter needs a consumer (read after MOONRT_PATH_NSUB)
         if ((e = std::getenv("MOONRT_PATH_QUEUE_MIN")) && std::atof(e) >= 0.0) c->path_queue_min = (uint64_t)std::atof(e);
         if ((e = std::getenv("MOONRT_TEST_PATH_NOMEM")) && std::atoi(e) == 1) c->path_alloc_fail_test = true;
@@ -941,7 +942,19 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     // launch: 12 GB for the whole-disc cfg3 frame, 129 GB for a cfg4 frame whose every pixel is on the Moon).  A frame
     // that needs more than path_budget_bytes is rendered in SUB-PARTS of its tile list, one after the other through the
     // same buffers: render(sub) -> paths(sub) -> resolve(sub); sub-parts cover disjoint pixels.
-    const uint64_t cap_chunks = std::max<uint64_t>(4096, c->path_budget_bytes / (64ull * MRTX_PATH_REC_BYTES));
+    // ... and never more than half of what the device has free right now (unless MOONRT_PATH_MAX_GB says otherwise): a second
+    // context, a torch process or a 34 GB cfg4 DEM on the same GPU must not turn the fixed budget into an allocation failure
+    uint64_t budget = c->path_budget_bytes;
+    if (!c->path_budget_env) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t held = (uint64_t)c->path_cap * (uint64_t)c->path_sets * 64ull * MRTX_PATH_REC_BYTES;   // what this context already holds counts as free
+            budget = std::min<uint64_t>(budget, std::max<uint64_t>(1ull << 28, ((uint64_t)free_b + held) / 2));
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    const uint64_t cap_chunks = std::max<uint64_t>(4096, budget / (64ull * MRTX_PATH_REC_BYTES));
     n_sub = 1;
     {
         const uint64_t full = mrtx_path_chunks(f, S, nullptr, nullptr);

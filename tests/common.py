@@ -10,7 +10,9 @@ STAT_KEYS = ("primary_rays", "primary_hits", "shadow_rays", "height_samples", "c
              "background_fetches", "bounce_rays", "bounce_sun_hits")
 
 
-def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, tile=(32, 32), flags=1, capsules=None):
+def render_hip(scene, dem, color=None, bg=None, blocks=(1,), rank=0, world=1, tile=(16, 16), flags=1, capsules=None):
+    """tile: 16 x 16 is what the library itself uses on one or two GPUs (round 3's default); tests that exercise other tilings pass
+    theirs."""
     rt = MoonRT(scene.width, scene.height, rank=rank, world=world, tile=tile)
     try:
         rt.upload_dem(dem)
