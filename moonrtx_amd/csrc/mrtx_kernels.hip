@@ -1078,7 +1078,10 @@ __device__ __forceinline__ bool sky_pixel_uniform(const FrameC& f, int x, int y,
 #ifndef MRTX_LDS_PARK
 #define MRTX_LDS_PARK 1
 #endif
-#define MRTX_PARK_SLOTS 3
+#ifndef MRTX_PARK_SHARE_ORIGIN
+#define MRTX_PARK_SHARE_ORIGIN 1     // the shadow ray and the continuation ray leave the SAME point (vertex + scene_epsilon * normal): its exact
+#endif                               // texel coordinates and horizon cell are evaluated once and sit out the shadow march in a fourth slot
+#define MRTX_PARK_SLOTS (MRTX_PARK_SHARE_ORIGIN ? 4 : 3)
 #ifndef MRTX_WG_WAVES
 #define MRTX_WG_WAVES 1       // waves per workgroup of render_kernel (see there)
 #endif
@@ -1326,6 +1329,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     }
 #endif
     uint32_t ksl = ks;      // the sample's RNG key as the continuation uses it (PARK: the copy that came back from LDS)
+    float org_row = 0.0f, org_col = 0.0f, org_cell = 0.0f;   // PARK + MRTX_PARK_SHARE_ORIGIN: the lifted vertex on the DEM grid
     for (;;) {
         PROF_BEGIN(5);
         float wgt;
@@ -1333,6 +1337,14 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
             // direct_light() with the vertex, the key and the carried radiance parked in LDS while the shadow ray marches
             float oa, ob, oc, wa, wb, wc, carried = 0.0f;
             const bool have_s = light_sample(f, v, ul1, ul2, oa, ob, oc, wa, wb, wc, carried);
+#if MRTX_PARK_SHARE_ORIGIN
+            // the origin's exact texel coordinates and horizon-mip cell: ONE evaluation / look-up for the shadow ray and, below,
+            // for the continuation ray (continue_path builds its origin with the very expression light_sample uses)
+            float q2o;
+            exact_rowcol(f, oa, ob, oc, org_row, org_col, q2o);
+            org_cell = CF(f)->hmip != nullptr ? horizon_cell(f, org_row, org_col) : 0.0f;
+            park_put(park, 3, org_row, org_col, org_cell, 0.0f);
+#endif
             park_put(park, 0, v.pa, v.pb, v.pc, v.na);
             park_put(park, 1, v.nb, v.nc, v.al0, v.al1);
             park_put(park, 2, v.al2, __uint_as_float(ksl), carried, 0.0f);
@@ -1342,9 +1354,19 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 if (STATS) cnt[ST_SHADOW]++;
                 Seg ssg;
                 float sk_occ;
+#if MRTX_PARK_SHARE_ORIGIN
+                MarchState ms;
+                ms.rowA = org_row; ms.colA = org_col;
+                bool sgo = march_begin_at<false, STATS, false, true>(f, oa, ob, oc, wa, wb, wc, ms, cnt, org_cell);
+                while (sgo) march_segment<WIDE, false, STATS, BATCH>(f, ms, 0.0f, ssg, sgo, occluded, sk_occ, cnt);
+#else
                 occluded = march<WIDE, false, STATS, BATCH>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt);
+#endif
             }
             park_fence();
+#if MRTX_PARK_SHARE_ORIGIN
+            { const v4f p3 = park_get(park, 3); org_row = p3.x; org_col = p3.y; org_cell = p3.z; }
+#endif
             const v4f p0 = park_get(park, 0), p1 = park_get(park, 1), p2 = park_get(park, 2);
             v.pa = p0.x; v.pb = p0.y; v.pc = p0.z; v.na = p0.w;
             v.nb = p1.x; v.nc = p1.y; v.al0 = p1.z; v.al1 = p1.w;
@@ -1362,8 +1384,13 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
             // whether to continue, build their continuation rays and locate the ray origins on the DEM grid -- is done
             // here at full occupancy; the queue record is a ray that is ready to march.
             if (continue_path(f, v, ksl, 1u, t0r, t1r, t2r, o.oa, o.ob, o.oc, o.da, o.db, o.dc)) {
-                float q2;
-                exact_rowcol(f, o.oa, o.ob, o.oc, o.row, o.col, q2);
+                constexpr bool SHARED = PARK && MRTX_PARK_SHARE_ORIGIN != 0;
+                if (SHARED) {
+                    o.row = org_row; o.col = org_col;
+                } else {
+                    float q2;
+                    exact_rowcol(f, o.oa, o.ob, o.oc, o.row, o.col, q2);
+                }
                 o.t0 = t0r; o.t1 = t1r; o.t2 = t2r;
                 o.ks = ksl; o.aux = 0u;
                 if (STATS) cnt[ST_BOUNCE]++;
@@ -1392,7 +1419,9 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                     park_put(park, 1, o.t1, o.t2, __uint_as_float(o.ks), 0.0f);
                     park_fence();
                 }
-                bool tgo = march_begin_at<false, STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, tm, tcnt), thit = false;
+                bool tgo = SHARED ? march_begin_at<false, STATS, false, true>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, tm, tcnt, org_cell)
+                                  : march_begin_at<false, STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, tm, tcnt);
+                bool thit = false;
                 Seg tsg;
                 float tsk = 0.0f;
                 if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH, MRTX_TRIAL_CP>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
