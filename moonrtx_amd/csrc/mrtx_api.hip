@@ -945,7 +945,8 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
     // ... and never more than half of what the device has free right now (unless MOONRT_PATH_MAX_GB says otherwise): a second
     // context, a torch process or a 34 GB cfg4 DEM on the same GPU must not turn the fixed budget into an allocation failure
     uint64_t budget = c->path_budget_bytes;
-    if (!c->path_budget_env) {
+    const uint64_t full_chunks = mrtx_path_chunks(f, S, nullptr, nullptr);
+    if (!c->path_budget_env && full_chunks > c->path_cap) {      // asked only when the buffers have to grow (a driver call: not per frame)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const uint64_t held = (uint64_t)c->path_cap * (uint64_t)c->path_sets * 64ull * MRTX_PATH_REC_BYTES;   // what this context already holds counts as free
@@ -954,10 +955,10 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
             (void)hipGetLastError();
         }
     }
-    const uint64_t cap_chunks = std::max<uint64_t>(4096, budget / (64ull * MRTX_PATH_REC_BYTES));
+    const uint64_t cap_chunks = std::max<uint64_t>(std::max<uint64_t>(4096, budget / (64ull * MRTX_PATH_REC_BYTES)), c->path_cap);
     n_sub = 1;
     {
-        const uint64_t full = mrtx_path_chunks(f, S, nullptr, nullptr);
+        const uint64_t full = full_chunks;
         if (full > cap_chunks && f.tile_list != nullptr) n_sub = (int)std::min<uint64_t>((uint64_t)f.n_active, (full + cap_chunks - 1) / cap_chunks);
     }
     overlap = c->path_overlap > 1 && f.tile_list != nullptr && f.n_active >= 8 * c->path_overlap && !stats;
