@@ -260,6 +260,12 @@ int mrtx_probe_stream(int32_t device, uint64_t bytes, int32_t repeats);
 int mrtx_probe_latlon(int32_t device, const float* a, const float* b, const float* c, float* lat, float* lon,
                       int32_t n);
 
+/* Math conformance probe (ABI 7): the kernels' domain-restricted reciprocal (v_rcp_f32 + Newton steps) and square root (v_sqrt_f32 + a
+ * +-1 ulp residual fix) against the compiler's IEEE expansions of 1.0f / x and sqrtf(x), ON THE DEVICE, for the n float bit patterns
+ * from lo_bits on: which = 0 one Newton step, 1 two steps (what the kernels use), 2 the square root.  mismatches = how many differ;
+ * first_bad_bits = the smallest bit pattern that does (0 if none).  The whole domain is 2^32 patterns: seconds. */
+int mrtx_probe_cr(int32_t device, int32_t which, uint32_t lo_bits, uint64_t n, uint64_t* mismatches, uint32_t* first_bad_bits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mrtx_dev_download": (C.c_int, [C.c_int32, _VP, _VP, C.c_uint64]),
     "mrtx_dev_upload": (C.c_int, [C.c_int32, _VP, _VP, C.c_uint64]),
     "mrtx_probe_stream": (C.c_int, [C.c_int32, C.c_uint64, C.c_int32]),
+    "mrtx_probe_cr": (C.c_int, [C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "mrtx_probe_latlon": (C.c_int, [C.c_int32, _VP, _VP, _VP, _VP, _VP, C.c_int32]),
 }
 

@@ -48,6 +48,7 @@ hipError_t mrtx_launch_mip_pairs(const float* mip, float* out_pairs, int rows, i
 hipError_t mrtx_launch_hmip(const float* mip, int mh, int mw, int shift, float* out, int hh, int hw, int hshift, int h, int w,
                             hipStream_t st);
 hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out, hipStream_t st);
+hipError_t mrtx_launch_probe_cr(uint32_t lo, uint64_t n, int which, unsigned long long* out2, hipStream_t st);
 
 struct mrtx_ctx {
     MrtxConfig cfg{};
@@ -1479,6 +1480,22 @@ int mrtx_probe_stream(int32_t device, uint64_t bytes, int32_t repeats) {
     if (rc == MRTX_OK && hipDeviceSynchronize() != hipSuccess) rc = MRTX_E_DEVICE;
     if (buf) (void)hipFree(buf);
     if (out) (void)hipFree(out);
+    return rc;
+}
+int mrtx_probe_cr(int32_t device, int32_t which, uint32_t lo_bits, uint64_t n, uint64_t* mismatches, uint32_t* first_bad_bits) {
+    if (which < 0 || which > 2 || n == 0 || !mismatches) return MRTX_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return MRTX_E_DEVICE;
+    unsigned long long* d = nullptr;
+    unsigned long long h[2] = {0ull, ~0ull};
+    int rc = MRTX_OK;
+    if (hipMalloc((void**)&d, sizeof h) != hipSuccess) return MRTX_E_NOMEM;
+    if (hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess ||
+        mrtx_launch_probe_cr(lo_bits, n, which, d, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = MRTX_E_DEVICE;
+    (void)hipFree(d);
+    *mismatches = h[0];
+    if (first_bad_bits) *first_bad_bits = h[1] == ~0ull ? 0u : (uint32_t)(h[1] - 1ull);
     return rc;
 }
 int mrtx_probe_latlon(int32_t device, const float* a, const float* b, const float* c, float* lat, float* lon,

@@ -89,6 +89,43 @@ __device__ __forceinline__ float sqrt_cr(float x) {
     return s;
 }
 
+// Correctly rounded 1/x for every NORMAL x whose reciprocal is normal (|x| in [2^-126, 2^126)): v_rcp_f32 (<= 1 ulp) + one Newton
+// step with an exact fma residual -- 3 VALU instead of the 10 of the general division expansion (v_div_scale x 2, v_rcp, four fmas,
+// v_div_fmas, v_div_fixup), which exists to survive operands and quotients at the ends of the exponent range.  Equality with the
+// IEEE quotient 1.0f / x is not argued, it is CHECKED: mrtx_probe_cr() compares the two on the device for EVERY normal float of
+// either sign (2^32 bit patterns, under a second; profiles/r04_probe_cr.txt): 0 mismatches for exponents -126 .. 125, all of them
+// where 1/x is subnormal or x = 0 (tests/test_gpu_parity.py::test_domain_restricted_reciprocal_and_sqrt_are_ieee_exact).
+// sqrt_cr() likewise: 0 mismatches for x = 0 and exponents -104 .. 127.  Callers keep their arguments inside these domains (each
+// call site says why); the oracle uses the C compiler's IEEE division and sqrtf throughout.
+#ifndef MRTX_RCP_STEPS
+#define MRTX_RCP_STEPS 1      // measured exhaustively: ONE step is already exact wherever x and 1/x are normal (profiles/r04_probe_cr.txt)
+#endif
+#ifndef MRTX_FAST_CR
+#define MRTX_FAST_CR 1      // 0 = the compiler's IEEE expansions everywhere (A/B switch; the results are the same bits)
+#endif
+template <int STEPS = 2>
+__device__ __forceinline__ float rcp_nr(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+#pragma unroll
+    for (int i = 0; i < STEPS; i++) { const float e = fmaf(-x, y, 1.0f); y = fmaf(e, y, y); }
+    return y;
+}
+__device__ __forceinline__ float rcp_cr(float x) {
+#if MRTX_FAST_CR
+    return rcp_nr<MRTX_RCP_STEPS>(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// sqrt for the shading code: sqrt_cr where the argument is inside its domain (or exactly zero, which it returns as zero)
+__device__ __forceinline__ float sqrt_sh(float x) {
+#if MRTX_FAST_CR
+    return sqrt_cr(x);
+#else
+    return sqrtf(x);
+#endif
+}
+
 // (a, b, c) -> lat = atan2(c, rho), lon = atan2(a, b), rho = sqrt(max(a^2+b^2, 1e-28)).  The two min/max
 // ratios share ONE correctly rounded reciprocal (a v_div_scale/v_rcp/fma/v_div_fixup chain is ~12 VALU);
 // min/max instead of compare+select keeps VCC hazards (s_nop) out of the loop.
@@ -98,7 +135,7 @@ __device__ __forceinline__ void latlon(float a, float b, float c, float rho2, fl
     const float m1 = fmaxf(rho, ac), n1 = fminf(rho, ac);
     const float m2 = fmaxf(ab, aa), n2 = fminf(ab, aa);
     const float den = fmaxf(m1 * m2, 1.0e-37f);
-    const float t = 1.0f / den;
+    const float t = rcp_cr(den);            // den in [1e-37, ~1e7]: normal, reciprocal normal
     float r1 = atan_poly(n1 * (t * m2));
     float r2 = atan_poly(n2 * (t * m1));
     r1 = ac >= rho ? kHalfPi - r1 : r1;
@@ -663,7 +700,7 @@ struct Vertex {
 __device__ __forceinline__ void duff_basis(float na, float nb, float nc, float& b1a, float& b1b, float& b1c, float& b2a,
                                            float& b2b, float& b2c) {
     const float sg = nc >= 0.0f ? 1.0f : -1.0f;
-    const float aa = -1.0f / (sg + nc);
+    const float aa = -rcp_cr(sg + nc);       // |sg + nc| in [1, 2]; -(1/x) == (-1)/x bit for bit
     const float bb = (na * nb) * aa;
     b1a = fmaf(sg, (na * na) * aa, 1.0f); b1b = sg * bb; b1c = -sg * na;
     b2a = bb; b2b = fmaf(nb * nb, aa, sg); b2c = -nb;
@@ -693,8 +730,8 @@ template <bool STATS, bool WIDE>
 __device__ __forceinline__ void hit_vertex(const FrameC& f, float ha, float hb, float hc, Vertex& v, uint32_t* cnt) {
     const float rho2 = fmaf(hb, hb, ha * ha);
     const float r2 = fmaf(hc, hc, rho2);
-    const float rho = sqrtf(rho2);
-    const float r = sqrtf(r2);
+    const float rho = sqrt_sh(rho2);         // only used through rhoc = max(rho, 1e-6): a rho2 below 2^-104 cannot matter
+    const float r = sqrt_sh(r2);             // r2 ~ R^2
     float lat, lon;
     latlon(ha, hb, hc, rho2, lat, lon);
     const float rowf = fmaf(lat, f.gd.row_scale, f.gd.row_off);
@@ -708,7 +745,7 @@ __device__ __forceinline__ void hit_vertex(const FrameC& f, float ha, float hb, 
     const float dlat = (dn - ds) * CF(f)->dlat_scale;
     const float dlon = (de - dw) * CF(f)->dlon_scale;
     const float rhoc = rho > 1.0e-6f ? rho : 1.0e-6f;
-    const float inv_r = 1.0f / r, inv_rho = 1.0f / rhoc;
+    const float inv_r = rcp_cr(r), inv_rho = rcp_cr(rhoc);   // r ~ R, rhoc in [1e-6, R]
     const float sphi = hc * inv_r, cphi = rhoc * inv_r;
     const float slam = ha * inv_rho, clam = hb * inv_rho;
     const float glat = (f.Rf * inv_r) * dlat;
@@ -716,7 +753,7 @@ __device__ __forceinline__ void hit_vertex(const FrameC& f, float ha, float hb, 
     const float na = fmaf(-glon, clam, fmaf(glat, sphi * slam, ha * inv_r));
     const float nb = fmaf(glon, slam, fmaf(glat, sphi * clam, hb * inv_r));
     const float nc = fmaf(-glat, cphi, hc * inv_r);
-    const float inv_nl = 1.0f / sqrtf(fmaf(nc, nc, fmaf(nb, nb, na * na)));
+    const float inv_nl = rcp_cr(sqrt_sh(fmaf(nc, nc, fmaf(nb, nb, na * na))));   // |n|^2 >= ~1 (unit radial part + gradient)
     v.pa = ha; v.pb = hb; v.pc = hc;
     v.na = na * inv_nl; v.nb = nb * inv_nl; v.nc = nc * inv_nl;
     if (CF(f)->color) {  // D4: bilinear RGBA8
@@ -755,15 +792,15 @@ __device__ __forceinline__ bool light_sample(const FrameC& f, const Vertex& v, f
     oa = fmaf(eps, v.na, v.pa); ob = fmaf(eps, v.nb, v.pb); oc = fmaf(eps, v.nc, v.pc);
     const float ta = CF(f)->Lb[0] - oa, tb = CF(f)->Lb[1] - ob, tc = CF(f)->Lb[2] - oc;
     const float d2 = fmaf(tc, tc, fmaf(tb, tb, ta * ta));
-    const float inv_dist = 1.0f / sqrtf(d2);
+    const float inv_dist = rcp_cr(sqrt_sh(d2));   // distance to the light: ~2e4 R
     const float la = ta * inv_dist, lb = tb * inv_dist, lc = tc * inv_dist;
     float sin2 = CF(f)->rL2 * (inv_dist * inv_dist);
     if (sin2 > 1.0f) sin2 = 1.0f;
-    const float cosmax = sqrtf(1.0f - sin2);
+    const float cosmax = sqrt_sh(1.0f - sin2);     // 0 or >= 2^-24
     const float omc = sin2 / (1.0f + cosmax);
     const float av = u2 * omc;
     const float cost = 1.0f - av;
-    const float sint = sqrtf(av * (2.0f - av));
+    const float sint = sqrt_sh(av * (2.0f - av));  // 0 (u2 = 0 or a point light) or >= ~2^-24 * omc
     float cph, sph;
     sincos_turn(u3, cph, sph);
     float b1a, b1b, b1c, b2a, b2b, b2c;
@@ -804,11 +841,11 @@ __device__ __forceinline__ bool continue_path(const FrameC& f, const Vertex& v, 
         pcont = pcont > v.al2 ? pcont : v.al2;
         pcont = pcont > 1.0f ? 1.0f : pcont;
         if (!(u01(ks, d0) < pcont)) return false;
-        const float ip = 1.0f / pcont;
+        const float ip = rcp_cr(pcont);           // pcont in (0, 1]: a reflectance (u01 < pcont held, so pcont > 0), never subnormal
         t0r *= ip; t1r *= ip; t2r *= ip;
     }
     const float uh1 = u01(ks, d0 + 1u), uh2 = u01(ks, d0 + 2u);
-    const float rr = sqrtf(uh1), zz = sqrtf(1.0f - uh1);
+    const float rr = sqrt_sh(uh1), zz = sqrt_sh(1.0f - uh1);   // uh1 = m * 2^-24: 0 or >= 2^-24
     float cph, sph;
     sincos_turn(uh2, cph, sph);
     float b1a, b1b, b1c, b2a, b2b, b2c;
@@ -1035,7 +1072,7 @@ __device__ __forceinline__ void env_rowcol(const FrameC& f, float fx, float fy, 
     float dx = fmaf(sy, CF(f)->Vy[0], fmaf(sx, CF(f)->Ux[0], CF(f)->Wd[0]));
     float dy = fmaf(sy, CF(f)->Vy[1], fmaf(sx, CF(f)->Ux[1], CF(f)->Wd[1]));
     float dz = fmaf(sy, CF(f)->Vy[2], fmaf(sx, CF(f)->Ux[2], CF(f)->Wd[2]));
-    const float inv_len = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    const float inv_len = rcp_cr(sqrt_sh(fmaf(dz, dz, fmaf(dy, dy, dx * dx))));   // |Wd + sx Ux + sy Vy|^2 in [1, 1 + tan^2]
     dx = dx * inv_len; dy = dy * inv_len; dz = dz * inv_len;
     float el, az;
     latlon(dx, dy, dz, fmaf(dy, dy, dx * dx), el, az);
@@ -1143,7 +1180,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     float dx = fmaf(sy, CF(f)->Vy[0], fmaf(sx, CF(f)->Ux[0], CF(f)->Wd[0]));
     float dy = fmaf(sy, CF(f)->Vy[1], fmaf(sx, CF(f)->Ux[1], CF(f)->Wd[1]));
     float dz = fmaf(sy, CF(f)->Vy[2], fmaf(sx, CF(f)->Ux[2], CF(f)->Wd[2]));
-    const float inv_len = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    const float inv_len = rcp_cr(sqrt_sh(fmaf(dz, dz, fmaf(dy, dy, dx * dx))));   // |Wd + sx Ux + sy Vy|^2 in [1, 1 + tan^2]
     dx = dx * inv_len; dy = dy * inv_len; dz = dz * inv_len;
     if (MODE == 3) {
         if (CF(f)->bg) env_lookup<STATS>(f, dx, dy, dz, o.c0, o.c1, o.c2, cnt);  // D7
@@ -1162,7 +1199,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         // products/sums in float64; the root and the 1/a scale in float32 (f64 sqrt and division are ~35
         // instructions each): their rounding moves the entry point along the ray only
         const double sq = (double)sqrtf((float)disc);
-        const double inva = (double)(1.0f / (float)a);
+        const double inva = (double)rcp_cr((float)a);      // a = |d|^2 = 1 +- rounding
         t0 = (-b - sq) * inva;
         t1 = (-b + sq) * inva;
         if (t1 > 0.0) { on_sphere = true; if (t0 < 0.0) t0 = 0.0; }
@@ -1174,7 +1211,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
     double tc0 = 0.0;
     bool cap_front = false;
     if (OVERLAY) {
-        tc0 = -b * (double)(1.0f / (float)a);
+        tc0 = -b * (double)rcp_cr((float)a);
         cr0 = (float)(CF(f)->oc[0] + tc0 * Dx); cr1 = (float)(CF(f)->oc[1] + tc0 * Dy); cr2 = (float)(CF(f)->oc[2] + tc0 * Dz);
         cap_s = nearest_capsule(f, lt, cr0, cr1, cr2, dx, dy, dz, (float)(-tc0), cap);   // nearest one in front of the eye
         cap_front = cap >= 0 && (!on_sphere || cap_s < (float)(t0 - tc0));
@@ -1499,7 +1536,8 @@ __device__ __forceinline__ float tree_sum(float v) {
 #define MRTX_SKY_WG_TILE 8    // MODE 3: a wave walks an 8x8-pixel block (a sky sample is ~150 instructions: one pixel per
 #endif                        // workgroup is bound by the dispatcher, 1.9 ms for the 5 000 sky tiles of cfg3 + star map)
 #ifndef MRTX_MIN_WAVES
-#define MRTX_MIN_WAVES 4   // 4 waves/SIMD (128-VGPR budget): 13.57 ms at cfg3 against 13.87 with 5 (96), 14.8 with 6; 3 = 4
+#define MRTX_MIN_WAVES 4   // an upper bound on registers only: since a launch traces one block (round 4) the direct kernel needs 69 VGPRs
+                           // whatever the bound says -- 7 waves per SIMD (rounds 1-3: 94 VGPRs, 13.57 ms at cfg3 with 4, 13.87 with 5)
 #endif
 #ifndef MRTX_XCD_SHARE
 #define MRTX_XCD_SHARE 1   // 0 = always whole tiles per XCD (A/B switch, see the remap in render_kernel)
@@ -1529,7 +1567,9 @@ __device__ __forceinline__ float tree_sum(float v) {
 #define MRTX_BOUNCE_WAVES(STATS, SV) ((STATS) ? MRTX_BOUNCE_STATS_WAVES : ((SV) <= 2 ? 4 : MRTX_MIN_WAVES_BOUNCE))
 template <int S, bool STATS, bool WIDE, int MODE, bool OVERLAY>
 #ifndef MRTX_MIN_WAVES_DEFER
-#define MRTX_MIN_WAVES_DEFER 3   // 15.3 ms at cfg3 against 17.1 with 4 and 19.3 with 5 (hand-over stores + cache footprint)
+#define MRTX_MIN_WAVES_DEFER 3   // no longer what sets the occupancy: with one block per launch and its cold state parked in LDS the kernel
+                                 // needs 62 VGPRs under any bound up to 8 -- 8 waves per SIMD (rounds 2-3: 121-125 VGPRs, 4 waves; a bound of
+                                 // 5 then meant 17 spilled registers and 22.2 ms against 18.9)
 #endif
 __global__ void __launch_bounds__(64 * MRTX_WG_WAVES, MODE == 1 ? MRTX_BOUNCE_WAVES(STATS, S) : MODE == 2 ? MRTX_MIN_WAVES_DEFER : MRTX_MIN_WAVES)
 render_kernel(const FrameC f, const PathQ pq) {
@@ -2195,11 +2235,14 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
 
 // The radiance sums of the deferred pixels: the S final sample values of a pixel added in the butterfly order of the
 // spec (block sum), then onto the running sum -- exactly what render_kernel does in registers.
+#ifndef MRTX_RESOLVE_U
+#define MRTX_RESOLVE_U 4      // chunks a wave keeps in flight (4 KB of sample values); the launch sizes its grid with it
+#endif
 template <int S>
 __global__ void __launch_bounds__(256) resolve_paths_kernel(const FrameC f, const PathQ pq) {
     // A wave takes U consecutive chunks at a time: their meta words in one round, then every load of the deferred ones (sample
     // values and running sums) in a second -- the kernel is a pure stream, bound by the bytes it keeps in flight.
-    constexpr uint32_t U = 4;
+    constexpr uint32_t U = MRTX_RESOLVE_U;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t pp = lane >> pq.s_log2, ss = lane & ((1u << pq.s_log2) - 1u);
     for (uint32_t base = (blockIdx.x * 4u + wv) * U; base < pq.n_chunks; base += gridDim.x * 4u * U) {
@@ -2520,6 +2563,31 @@ __global__ void probe_latlon_kernel(const float* a, const float* b, const float*
     if (i < n) latlon(a[i], b[i], c[i], fmaf(b[i], b[i], a[i] * a[i]), lat[i], lon[i]);
 }
 
+// Exhaustive check of the domain-restricted primitives against the compiler's IEEE expansions, on the device, for the bit patterns
+// [lo, lo + n): which = 0: rcp_nr<1>(x) vs 1.0f / x; 1: rcp_nr<2>(x); 2: sqrt_cr(x) vs sqrtf(x).  out[0] = mismatches, out[1] = the
+// smallest mismatching bit pattern + 1 (0 = none).
+__global__ void probe_cr_kernel(uint32_t lo, uint64_t n, int which, unsigned long long* __restrict__ out) {
+    unsigned long long bad = 0, first = ~0ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bits = lo + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        float a, b;
+        if (which == 2) { a = sqrtf(x); b = sqrt_cr(x); }
+        else { a = 1.0f / x; b = which == 0 ? rcp_nr<1>(x) : rcp_nr<2>(x); }
+        if (__float_as_uint(a) != __float_as_uint(b)) { bad++; first = first < bits ? first : (unsigned long long)bits; }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        bad += __shfl_xor(bad, m, 64);
+        const unsigned long long o = __shfl_xor(first, m, 64);
+        first = first < o ? first : o;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicAdd(&out[0], bad);
+        if (first != ~0ull) atomicMin(&out[1], first + 1ull);
+    }
+}
+
 // DEM (h, w) row-major -> padded (h+4, w+4): rows clamp, columns wrap (see dem_march)
 __global__ void pad_dem_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w) {
     const int pitch = w + 4;
@@ -2737,7 +2805,7 @@ hipError_t mrtx_launch_paths(const FrameC& f, const PathQ& pq, int S, bool stats
            else hipLaunchKernelGGL((mrtx::path_kernel<false, false>), grid, block, 0, st, f, pq); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    unsigned rb = (pq.n_chunks + 15u) / 16u;   // 4 waves x 4 chunks per block and turn
+    unsigned rb = (pq.n_chunks + 4u * MRTX_RESOLVE_U - 1u) / (4u * MRTX_RESOLVE_U);   // 4 waves x U chunks per block and turn
     if (rb > 65536u) rb = 65536u;
     const dim3 rgrid(rb), rblock(256);
     switch (S) {
@@ -2851,6 +2919,10 @@ hipError_t mrtx_launch_synth_color(uint32_t* dst, int h, int w, uint32_t seed, h
 hipError_t mrtx_launch_probe_latlon(const float* a, const float* b, const float* c, float* lat, float* lon, int n,
                                     hipStream_t st) {
     hipLaunchKernelGGL(mrtx::probe_latlon_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, lat, lon, n);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_probe_cr(uint32_t lo, uint64_t n, int which, unsigned long long* out2, hipStream_t st) {
+    hipLaunchKernelGGL(mrtx::probe_cr_kernel, dim3(8192), dim3(256), 0, st, lo, n, which, out2);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_probe_stream(const void* src, int64_t n_pairs, float* out, hipStream_t st) {

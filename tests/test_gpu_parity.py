@@ -50,6 +50,27 @@ def test_math_primitives_bit_exact(native_lib):
     assert np.abs(lon_o[:n] - np.arctan2(p64[:, 0], p64[:, 1])).max() < 6e-7
 
 
+def test_domain_restricted_reciprocal_and_sqrt_are_ieee_exact(native_lib):
+    """The kernels take 1/x as v_rcp_f32 + one Newton step and sqrt as v_sqrt_f32 + a residual fix where the argument's range is
+    known (mrtx_kernels.hip: rcp_cr, sqrt_cr); the oracle uses the C compiler's IEEE division and sqrtf.  Equality is checked
+    EXHAUSTIVELY on the device against the compiler's IEEE expansions: every normal float of either sign whose reciprocal is normal
+    (exponents -126 .. 125), and every float from 2^-104 up plus zero for the square root."""
+    import ctypes as C
+    def probe(which, lo_bits, n):
+        bad, first = C.c_uint64(), C.c_uint32()
+        assert native_lib.mrtx_probe_cr(0, which, lo_bits, n, C.byref(bad), C.byref(first)) == 0
+        return bad.value, first.value
+    for sign in (0, 1):                                                  # reciprocal, one Newton step (what ships)
+        lo = (sign << 31) | (1 << 23)                                    # exponent field 1 (2^-126) ... 252 (2^125), all mantissas
+        assert probe(0, lo, (252 << 23)) == (0, 0)
+        assert probe(1, lo, (252 << 23)) == (0, 0)                       # two steps: the same
+    bad, first = probe(0, 253 << 23, 1 << 23)                            # 2^126 and beyond: 1/x is subnormal -- outside the domain
+    assert bad > 0 and first >= (253 << 23)
+    assert probe(2, 0, 1) == (0, 0)                                      # sqrt_cr(+0) = 0
+    assert probe(2, (127 - 104) << 23, (255 << 23) - ((127 - 104) << 23)) == (0, 0)      # 2^-104 ... the largest finite float
+    assert probe(2, 1 << 23, 1 << 23)[0] > 0                             # 2^-126: outside sqrt_cr's domain (never passed in)
+
+
 @pytest.mark.parametrize("name", ["S1", "S2", "S3"])
 def test_first_light_1spp(native_lib, dem_small, name):
     """BASELINE config 1 shape: 1 spp, grey albedo (reduced image so the oracle takes seconds)."""
