@@ -466,7 +466,11 @@ def main():
             kernels["path_kernel<false, %s> + resolve_paths_kernel<%d>" % (wide, S)] = {
                 "ms": round(paths_ms, 3), "algorithmic_bytes": int(p_bytes),
                 "achieved": round(p_bytes / (paths_ms * 1e-3) / 1e9, 1), "frac": round(p_bytes / (paths_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "does": "continuation-ray marches, later vertices and their shadow rays (persistent waves fed from the record queue), per-pixel sums"}
+                "does": "continuation-ray marches, later vertices and their shadow rays (persistent waves fed from the record queue), per-pixel sums",
+                "limited_by_note": "its traffic beyond the L2s is ~0.74 of the HBM peak, but it is not bound by those bytes: a bit-exact build that "
+                                   "proves 74 % of its march steps unnecessary from a finer max-mip (-DMRTX_PATH_MIP2=1) moves 14 GB instead of 26 GB per "
+                                   "frame and takes 4.53 ms instead of 4.35 (round 4, DESIGN.md section 4.6): the chain of dependent memory rounds a "
+                                   "persistent wave goes through is the bound, with the memory system close to saturation at the same time"}
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["ms"])
             dom_bytes, dom_ms = kernels[dom]["algorithmic_bytes"], kernels[dom]["ms"]

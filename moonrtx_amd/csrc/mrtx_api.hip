@@ -89,6 +89,7 @@ struct mrtx_ctx {
     float* tone16_dev = nullptr; float tone16_gamma = 0.0f;
     float* dem = nullptr; int dem_h = 0, dem_w = 0;   // padded (h+4) x (w+4) copy, always owned
     float* hmip = nullptr; int hm_h = 0, hm_w = 0, hm_shift = 0;       // horizon mip: cells of 8 max-mip cells, dilated by one cell (see horizon_kend)
+    float* mip2 = nullptr; int m2_h = 0, m2_w = 0, m2_shift = 0;       // medium max-mip: cells a quarter of the max-mip's (path_kernel's step mask)
     float* mip = nullptr; int mip_h = 0, mip_w = 0, mip_shift = 0;   // max-mip of it, cell 2^mip_shift texels (+ one-cell border)
     uint8_t* color = nullptr; bool color_owned = false; int color_h = 0, color_w = 0;
     uint8_t* bg = nullptr; int bg_h = 0, bg_w = 0;
@@ -311,6 +312,7 @@ void build_frame(const mrtx_ctx* c, FrameC& f, FrameCold& k) {
     f.dem = c->dem; k.color = c->color; k.bg = c->bg;
     k.hmip = (c->prm.flags & MRTX_F_NO_SKIP) ? nullptr : c->hmip; k.hm_h = c->hm_h; k.hm_w = c->hm_w; k.hm_shift = c->hm_shift;
     k.hm_cell = (float)(1 << c->hm_shift);
+    k.mip2 = (c->prm.flags & MRTX_F_NO_SKIP) ? nullptr : c->mip2; k.m2_pitch = c->m2_w + 2; k.m2_h = c->m2_h; k.m2_w = c->m2_w; k.m2_shift = c->m2_shift;
     k.hm_krow = (float)((double)c->dem_h / kPiD);
     k.hm_kcol = (float)(1.05 * (double)c->dem_w / (2.0 * kPiD));
     f.mip = c->mip; f.mip_pitch = c->mip_w + 2; f.mip_h = c->mip_h; f.mip_w = c->mip_w; f.mip_shift = c->mip_shift;
@@ -604,6 +606,7 @@ void mrtx_destroy(mrtx_ctx* c) {
     if (c->dem) (void)hipFree(c->dem);
     if (c->mip) (void)hipFree(c->mip);
     if (c->hmip) (void)hipFree(c->hmip);
+    if (c->mip2) (void)hipFree(c->mip2);
     if (c->color) (void)hipFree(c->color);
     if (c->bg) (void)hipFree(c->bg);
     if (c->overlay) (void)hipFree(c->overlay);
@@ -628,6 +631,8 @@ static int ingest_dem(mrtx_ctx* c, const float* dev_src, int32_t h, int32_t w) {
     c->mip = nullptr; c->mip_shift = 0;   // (re)built by mrtx_render for the march step in force
     if (c->hmip) { HIPCHK(c, hipFree(c->hmip)); }
     c->hmip = nullptr;
+    if (c->mip2) { HIPCHK(c, hipFree(c->mip2)); }
+    c->mip2 = nullptr;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dem_h = h; c->dem_w = w;
     return MRTX_OK;
@@ -644,6 +649,8 @@ static int ensure_mip(mrtx_ctx* c) {
     c->mip = nullptr;
     if (c->hmip) { HIPCHK(c, hipFree(c->hmip)); }
     c->hmip = nullptr;
+    if (c->mip2) { HIPCHK(c, hipFree(c->mip2)); }
+    c->mip2 = nullptr;
     const int cell = 1 << shift;
     c->mip_h = (c->dem_h + cell - 1) / cell; c->mip_w = (c->dem_w + cell - 1) / cell;
     const size_t cells = (size_t)(c->mip_h + 2) * (c->mip_w + 2);
@@ -656,6 +663,15 @@ static int ensure_mip(mrtx_ctx* c) {
     c->hm_h = (c->dem_h + (cell << 3) - 1) / (cell << 3); c->hm_w = (c->dem_w + (cell << 3) - 1) / (cell << 3);
     if (e == hipSuccess) e = hipMalloc((void**)&c->hmip, (size_t)c->hm_h * c->hm_w * sizeof(float));
     if (e == hipSuccess) e = mrtx_launch_hmip(plain, c->mip_h, c->mip_w, shift, c->hmip, c->hm_h, c->hm_w, c->hm_shift, c->dem_h, c->dem_w, c->stream);
+    // medium max-mip: the same cell maxima (dilated by the two-texel tap border) at a quarter of the cell size -- 16 texels at cfg3,
+    // 17 MB: what path_kernel tests the steps of a segment against before it fetches the DEM for them
+    c->m2_shift = shift - 2 < 2 ? 2 : shift - 2;
+    if (MRTX_PATH_MIP2) {
+        const int c2 = 1 << c->m2_shift;
+        c->m2_h = (c->dem_h + c2 - 1) / c2; c->m2_w = (c->dem_w + c2 - 1) / c2;
+        if (e == hipSuccess) e = hipMalloc((void**)&c->mip2, (size_t)(c->m2_h + 2) * (size_t)(c->m2_w + 2) * sizeof(float));
+        if (e == hipSuccess) e = mrtx_launch_mip(c->dem, c->dem_h, c->dem_w, c->mip2, c->m2_h, c->m2_w, c->m2_shift, c->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(plain);
     HIPCHK(c, e);

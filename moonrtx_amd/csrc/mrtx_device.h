@@ -45,6 +45,11 @@ static inline int mrtx_tile_shift(int world) {
     }
 }
 
+// path_kernel's medium-mip step mask (mrtx_kernels.hip: step_mask): 1 builds and uses it, 0 (default: it does not pay, see there) neither
+#ifndef MRTX_PATH_MIP2
+#define MRTX_PATH_MIP2 0
+#endif
+
 struct FrameCold {
     // D1 pinhole camera (moon_renderer.py:627-635)
     float Wd[3], Ux[3], Vy[3], two_over_w, two_over_h;
@@ -83,6 +88,10 @@ struct FrameCold {
     int32_t hm_h, hm_w, hm_shift;
     float hm_cell;                  // cell size in texels
     float hm_krow, hm_kcol;         // angle -> texel rows (h / pi); angle -> texel columns (1.05 w / 2 pi)
+    // medium max-mip (path_kernel's step mask, round 4): cells of 2^m2_shift texels (a quarter of the max-mip's), plain floats with a
+    // one-cell border like the max-mip before pairing -- (m2_h + 2) x (m2_w + 2) -- or null
+    const float* mip2;
+    int32_t m2_pitch, m2_h, m2_w, m2_shift;
 };
 
 struct FrameC {

@@ -1786,6 +1786,58 @@ __device__ unsigned long long g_pprof_t[16];   // [0..7] latest wave end per lab
 #endif
 enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_BISECT, PS_ENDED, PS_HITWAIT, PS_SHADE, PS_ESCAPED };
 
+// ---- path_kernel's step mask (round 4, MRTX_PATH_MIP2).  The kernel is bound by 128-byte line fills for 16-byte footprints, and half
+// of its L2 misses are march steps -- 85 % of which turn out to be more than 500 m above the terrain (round 3's margin histogram): the
+// max-mip that bounds a whole 16-step segment has cells of 64 texels at cfg3, far too coarse to see that.  The MEDIUM max-mip has
+// cells a quarter of that size (16 texels, 17 MB: L2 / Infinity-Cache resident, and consecutive steps share its lines); at segment
+// set-up every step the segment's skip interval kept is tested against the cell its footprint lies in -- r^2(s_k) > (R m)^2 (1 + 1e-5)
+// proves it above the surface, exactly as the coarse test does -- and only the steps that survive are evaluated (`todo`, one bit
+// per step).  Result-preserving like the other skips: radiance, hits and the spec counters are unchanged, MRTX_F_NO_SKIP switches
+// it off with the rest.  Fetched four steps at a time (one memory round per four tests).
+// MEASURED (cfg3, gpurun_out/r4w, prof_ab_m2on / m2off): the mask drops 74 % of path_kernel's step evaluations (151 M -> 39 M), its
+// L2 misses 215 M -> 121 M and its traffic beyond the L2s 26 -> 14 GB per frame -- and the kernel takes 4.53 ms instead of 4.35.  So
+// path_kernel is NOT bound by the bytes it moves (rounds 2-3 read "0.74 of the HBM peak" that way): what bounds it is the chain of
+// dependent memory rounds a wave goes through (the mask trades ~1.6 step rounds per set-up for ~1.5 medium-mip rounds + 0.6), with
+// the memory system merely close to saturation at the same time.  Off by default (MRTX_PATH_MIP2 in mrtx_device.h); kept as a switch
+// because it is bit-exact and halves the path stage's HBM traffic, which a bandwidth-starved configuration might want.
+#if MRTX_PATH_MIP2 && MRTX_PATH_WIDE
+#error "MRTX_PATH_WIDE walks j .. jhi contiguously: build it with -DMRTX_PATH_MIP2=0"
+#endif
+template <bool STATS>
+__device__ __forceinline__ uint32_t step_mask(const FrameC& f, const MarchState& m, const Seg& sg, uint32_t todo, uint32_t* cnt) {
+    typedef const __attribute__((address_space(1))) float* GFloat;
+    const float* m2 = CF(f)->mip2;
+    const int pitch = CF(f)->m2_pitch, sh = CF(f)->m2_shift, mh = CF(f)->m2_h, mw = CF(f)->m2_w;
+    uint32_t rem = todo, keep = 0u;
+    while (rem != 0u) {
+        int jj[4]; bool on[4]; float mv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            on[q] = rem != 0u;
+            jj[q] = on[q] ? (int)__builtin_ctz(rem) + 1 : 1;
+            rem &= rem - 1u;                                     // 0 stays 0
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float u = ((float)(m.ka + jj[q]) * f.step - sg.sa) * f.inv_step;      // as below_seg()
+            const float rowf = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra), colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
+            int i = ((int)floorf(rowf) >> sh) + 1, c = ((int)floorf(colf) >> sh) + 1;     // + 1: the one-cell border (floor = -1 -> cell -1)
+            i = max(0, min(i, mh + 1)); c = max(0, min(c, mw + 1));                      // never bites for a valid segment
+            mv[q] = on[q] ? m2[i * pitch + c] : 0.0f;
+        }
+        if (STATS) { cnt[ST_MIP] += (on[0] ? 1u : 0u) + (on[1] ? 1u : 0u) + (on[2] ? 1u : 0u) + (on[3] ? 1u : 0u); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float sk = (float)(m.ka + jj[q]) * f.step;
+            const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
+            const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
+            const float rd = f.Rf * mv[q];
+            if (on[q] && r2 <= (rd * rd) * 1.00001f) keep |= 1u << (jj[q] - 1);
+        }
+    }
+    return keep;
+}
+
 // The march inside path_kernel is cut at STEP granularity, not at segment granularity: within one 16-step segment
 // the rays of a wave need anything from 0 to 16 dependent DEM fetches (mean ~4), and a wave that steps a whole
 // segment per iteration waits for its slowest lane -- up to 16 memory round trips per iteration (measured: 17.6 ms
@@ -1794,9 +1846,31 @@ enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_BISECT, PS_ENDED, PS_HITWAIT, PS_SHA
 // VALU + the max-mip fetch) and STEP (its next step of the current segment is to be evaluated: ~45 VALU + one DEM
 // fetch); every iteration evaluates ONE step for all stepping lanes, and the set-up block runs when enough lanes
 // need it (or nobody is stepping).  Same evaluations, same order per ray as march_segment().
+// MRTX_PATH_PARK (round 4): the lanes' COLD state -- the current vertex (9 floats), the radiance its light sample carries, the path
+// throughput (3) and the sample's radiance so far (3) -- lives in LDS, four lane-private 16-byte slots (4 KB per wave), and is touched
+// only by the blocks that need it (refill, march over, the rare blocks).  path_kernel is bound by its waves' chains of dependent memory
+// rounds times the waves a SIMD holds (section 4.6 of DESIGN.md), so sixteen registers less looked like the price of a sixth wave.
+// MEASURED (cfg3, gpurun_out/r4x/path_park.log; path stage ms incl. resolve, two rounds): as shipped 4.98; parked at 5 waves (94
+// VGPRs, no scratch instead of 96 + 2 spilled) 4.98-5.04; at launch bounds 6 / 7 (80 / 72 VGPRs, 12 / 20 spilled: the set-up and
+// vertex blocks' temporaries are what fills the file, not the cold state) 5.36 / 6.10; with the step mask (MRTX_PATH_MIP2) on top
+// 4.97 / 5.00 / 4.96 at 5 / 6 / 7 waves.  Neither more resident waves, nor 46 % less traffic, nor both move the kernel: off (an A/B
+// switch; bit-exact, tools/quick_parity.py).
+#ifndef MRTX_PATH_PARK
+#define MRTX_PATH_PARK 0
+#endif
 template <bool STATS, bool WIDE>
 __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(const FrameC f, const PathQ pq) {
     const uint32_t lane = threadIdx.x;
+#if MRTX_PATH_PARK
+    __shared__ float pk_lds[4 * 64 * 4];
+    float* const pk = pk_lds + lane * 4u;              // slot s, component c of this lane: pk[s * 256 + c]
+#define PKS(s, c) pk[(s) * 256 + (c)]
+    // slot 0: v.pa pb pc na | 1: v.nb nc al0 al1 | 2: v.al2, carried, t0r, t1r | 3: t2r, c0, c1, c2
+#define COLD_GET_T(a, b, c) do { a = PKS(2, 2); b = PKS(2, 3); c = PKS(3, 0); } while (0)
+#define COLD_SET_T(a, b, c) do { PKS(2, 2) = a; PKS(2, 3) = b; PKS(3, 0) = c; } while (0)
+#define COLD_GET_C(a, b, c) do { a = PKS(3, 1); b = PKS(3, 2); c = PKS(3, 3); } while (0)
+#define COLD_SET_C(a, b, c) do { PKS(3, 1) = a; PKS(3, 2) = b; PKS(3, 3) = c; } while (0)
+#endif
     // Work distribution.  The records of render block b (b % 8 = a group label: blocks with one label ran on one XCD and
     // cover neighbouring pixels of the same tiles, see the remap in render_kernel) are taken in GROUPS of G consecutive
     // blocks of one label, handed out by atomic counters in device memory -- one set of counters per label of THIS
@@ -1837,16 +1911,23 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     MarchState m;
     Seg sg;
     int j = 1;                    // next step of the current segment (STEP lanes)
+    uint32_t todo = 0u;           // MRTX_PATH_MIP2: the steps of the current segment still to be evaluated, bit jj - 1 for step jj >= j
     float sk_hit = 0.0f;
+#if MRTX_PATH_PARK
+    float wgt = 0.0f;
+#else
     Vertex v;
     float t0r = 1.0f, t1r = 1.0f, t2r = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, carried = 0.0f, wgt = 0.0f;
+#endif
     // BISECT lanes (a continuation ray that hit: D3's bisection, one level per DEM fetch like any other step) keep the
     // bracket in registers that are dead meanwhile: lo in wgt, hi in sk_hit, the levels left in j
     float& bis_lo = wgt;
     float& bis_hi = sk_hit;
     m.oa = m.ob = m.oc = m.da = m.db = m.dc = 0.0f; m.rq.q0 = m.rq.b = m.rq.a = 0.0f; m.rowA = m.colA = m.q2A = 0.0f; m.ka = 0; m.kend = 0;
     sg.sa = sg.ra = sg.r1 = sg.r2 = sg.ca = sg.c1 = sg.c2 = 0.0f; sg.jlo = 1; sg.jhi = 0; sg.exact = false;
+#if !MRTX_PATH_PARK
     v.pa = v.pb = v.pc = v.na = v.nb = v.nc = v.al0 = v.al1 = v.al2 = 0.0f;
+#endif
 
     for (;;) {
         // Every lane waits for exactly one of four blocks -- refill, segment set-up, step, rare -- and the wave decides
@@ -1951,7 +2032,11 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 } else {
                     go = march_begin_at<false, STATS, true>(f, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, m, cnt);
                 }
+#if MRTX_PATH_PARK
+                COLD_SET_T(r1.z, r1.w, r2.x);
+#else
                 t0r = r1.z; t1r = r1.w; t2r = r2.x;
+#endif
                 ks = __float_as_uint(r2.w);
                 hit = false; shadow = false; have_c = false;
                 seg = 1;
@@ -1982,7 +2067,13 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                     m.rowA = rowB; m.colA = colB; m.q2A = q2B;   // the next segment starts where this one ends
                     sg.jhi = max(min(sg.jhi, m.kend - m.ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
                     j = sg.jlo;
+#if MRTX_PATH_MIP2
+                    todo = j <= sg.jhi ? (((2u << (sg.jhi - 1)) - 1u) & ~((1u << (j - 1)) - 1u)) : 0u;      // steps j .. jhi
+                    if (CF(f)->mip2 != nullptr && !sg.exact) todo = step_mask<STATS>(f, m, sg, todo, cnt);
+                    if (todo != 0u) state = PS_STEP; else segend = true;
+#else
                     if (j <= sg.jhi) state = PS_STEP; else segend = true;
+#endif
                 }
             }
         }
@@ -2068,9 +2159,26 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 float mrg[MRTX_PATH_STEPS];
 #endif
                 const float mid0 = 0.5f * (bis_lo + bis_hi);
+#if MRTX_PATH_MIP2
+                // the next MRTX_PATH_STEPS steps the mask kept (a lane with fewer left repeats its last one: a wasted fetch)
+                int js[MRTX_PATH_STEPS]; bool have[MRTX_PATH_STEPS];
+                {
+                    uint32_t t = todo;
+#pragma unroll
+                    for (int i = 0; i < MRTX_PATH_STEPS; i++) {
+                        have[i] = t != 0u;
+                        js[i] = have[i] ? (int)__builtin_ctz(t) + 1 : (i ? js[i - 1] : 1);
+                        t &= t - 1u;
+                    }
+                }
+#endif
 #pragma unroll
                 for (int i = 0; i < MRTX_PATH_STEPS; i++) {
+#if MRTX_PATH_MIP2
+                    const int k = m.ka + js[i];
+#else
                     const int k = m.ka + min(j + i, sg.jhi);                 // a step past jhi is read at jhi instead
+#endif
                     const float sk = bis ? (i == 1 ? 0.5f * (bis_lo + mid0) : mid0) : (float)k * f.step;
                     const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
                     const float r2 = fmaf(pc, pc, fmaf(pb, pb, pa * pa));
@@ -2101,6 +2209,18 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 }
 #pragma unroll
                 for (int i = 0; i < MRTX_PATH_STEPS; i++) {
+#if MRTX_PATH_MIP2
+                    if (act && have[i]) {
+                        // the steps the mask dropped between the last evaluated one and this one are spec steps all the same
+                        if (STATS) { cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, j, js[i] - 1); }
+                        if (STATS) { cnt[ST_HEIGHT] += in[i] ? 1u : 0u; cnt[ST_FETCH]++; }
+                        todo &= todo - 1u;
+                        j = js[i] + 1;
+                        if (in[i] & bel[i]) { hit = true; sk_hit = sks[i]; state = PS_ENDED; act = false; }
+                        else if (!in[i]) { state = PS_ENDED; act = false; }
+                        else if (todo == 0u) { segend = true; act = false; }
+                    }
+#else
                     if (act) {
                         if (STATS) { cnt[ST_HEIGHT] += in[i] ? 1u : 0u; cnt[ST_FETCH]++; }
 #ifdef MRTX_PROF_MARGIN
@@ -2111,6 +2231,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                         else if (!in[i]) { state = PS_ENDED; act = false; }
                         else if (j > sg.jhi) { segend = true; act = false; }
                     }
+#endif
                 }
             }
         }
@@ -2118,7 +2239,8 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         PPROF_T(11);
         // ---- end of a segment that is neither hit nor left: did the ray end inside the skipped tail?
         if (segend) {
-            if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, max(sg.jhi + 1, 1), SEG_N);
+            // STATS: the steps after the last evaluated one (j = the step after it, or jlo when none was evaluated)
+            if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, max(MRTX_PATH_MIP2 ? j : sg.jhi + 1, 1), SEG_N);
             const int k = m.ka + SEG_N;
             const float sk = (float)k * f.step;
             const float pa = fmaf(sk, m.da, m.oa), pb = fmaf(sk, m.db, m.ob), pc = fmaf(sk, m.dc, m.oc);
@@ -2133,6 +2255,33 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
 
         // ---- march over
         if (state == PS_ENDED) {
+#if MRTX_PATH_PARK
+            if (shadow) {
+                wgt = hit ? 0.0f : PKS(2, 1);
+                state = PS_SHADE;
+            } else if (hit) {
+                if (!have_c) { float a, b, c_; c_load(pq, e, a, b, c_); COLD_SET_C(a, b, c_); have_c = true; }
+                const int bk = (int)rintf(sk_hit * f.inv_step);
+                bis_lo = (float)(bk - 1) * f.step;       // bis_hi is sk_hit already
+                j = f.nbis;
+                if (STATS) { cnt[ST_HEIGHT] += (uint32_t)f.nbis; cnt[ST_FETCH] += (uint32_t)f.nbis; }
+                state = f.nbis > 0 ? PS_BISECT : PS_HITWAIT;
+            } else if (CF(f)->bg) {
+                state = PS_ESCAPED;
+            } else {
+                float e0, e1, e2, a = 0.0f, b = 0.0f, c_ = 0.0f;
+                bool in_reg = false;
+                if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {   // the Sun disk
+                    if (!have_c) { c_load(pq, e, a, b, c_); have_c = true; } else { COLD_GET_C(a, b, c_); }
+                    float t0, t1, t2;
+                    COLD_GET_T(t0, t1, t2);
+                    a = fmaf(t0, e0, a); b = fmaf(t1, e1, b); c_ = fmaf(t2, e2, c_);
+                    in_reg = true;
+                }
+                if (have_c) { if (!in_reg) COLD_GET_C(a, b, c_); c_store(pq, e, a, b, c_); }
+                state = PS_IDLE;
+            }
+#else
             if (shadow) {
                 wgt = hit ? 0.0f : carried;
                 state = PS_SHADE;
@@ -2158,6 +2307,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 if (have_c) c_store(pq, e, c0, c1, c2);
                 state = PS_IDLE;
             }
+#endif
         }
 
         // ---- the rare steps (~8 % of the paths reach them): a continuation ray that hit terrain gets its vertex and
@@ -2165,6 +2315,70 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
         // continued or ended (~250 VALU).  They wait until enough lanes need them -- or nothing is marching.
         PPROF_T(12);
         if (do_rare) {
+#if MRTX_PATH_PARK
+            if (state == PS_ESCAPED) {
+                float e0, e1, e2, a = 0.0f, b = 0.0f, c_ = 0.0f;
+                bool in_reg = false;
+                if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {
+                    float t0, t1, t2;
+                    COLD_GET_T(t0, t1, t2);
+                    // a black texel adds nothing (fmaf(t, 0, c) == c for finite t): the sample's radiance need not be touched
+                    const bool nothing = (e0 == 0.0f) & (e1 == 0.0f) & (e2 == 0.0f) & ((t0 + t1 + t2) < __builtin_inff());
+                    if (!nothing) {
+                        if (!have_c) { c_load(pq, e, a, b, c_); have_c = true; } else { COLD_GET_C(a, b, c_); }
+                        a = fmaf(t0, e0, a); b = fmaf(t1, e1, b); c_ = fmaf(t2, e2, c_);
+                        in_reg = true;
+                    }
+                }
+                if (have_c) { if (!in_reg) COLD_GET_C(a, b, c_); c_store(pq, e, a, b, c_); }
+                state = PS_IDLE;
+            }
+            if (state == PS_HITWAIT) {
+                const float blo = bis_lo;                  // the bisected bracket's upper side (PS_BISECT)
+                Vertex v;
+                hit_vertex<STATS, WIDE>(f, fmaf(blo, m.da, m.oa), fmaf(blo, m.db, m.ob), fmaf(blo, m.dc, m.oc), v, cnt);
+                PKS(0, 0) = v.pa; PKS(0, 1) = v.pb; PKS(0, 2) = v.pc; PKS(0, 3) = v.na;
+                PKS(1, 0) = v.nb; PKS(1, 1) = v.nc; PKS(1, 2) = v.al0; PKS(1, 3) = v.al1; PKS(2, 0) = v.al2;
+                seg++;
+                const uint32_t d0 = 4u + 5u * (seg - 2u);   // the dimensions drawn when this segment was started
+                const float ul1 = u01(ks, d0 + 3u), ul2 = u01(ks, d0 + 4u);
+                float soa, sob, soc, swa, swb, swc, carried;
+                if (light_sample(f, v, ul1, ul2, soa, sob, soc, swa, swb, swc, carried)) {
+                    PKS(2, 1) = carried;
+                    if (STATS) cnt[ST_SHADOW]++;
+                    const bool go = march_begin<false, STATS, true>(f, soa, sob, soc, swa, swb, swc, m, cnt);
+                    hit = false; shadow = true;
+                    state = go ? PS_NEEDSEG : PS_ENDED;
+                } else {
+                    wgt = 0.0f;
+                    state = PS_SHADE;
+                }
+            }
+            park_fence();       // the vertex a lane parked above is READ BACK below (not kept in registers across the blocks)
+            if (state == PS_SHADE) {
+                Vertex v;
+                v.pa = PKS(0, 0); v.pb = PKS(0, 1); v.pc = PKS(0, 2); v.na = PKS(0, 3);
+                v.nb = PKS(1, 0); v.nc = PKS(1, 1); v.al0 = PKS(1, 2); v.al1 = PKS(1, 3); v.al2 = PKS(2, 0);
+                float t0r, t1r, t2r, c0, c1, c2;
+                COLD_GET_T(t0r, t1r, t2r);
+                COLD_GET_C(c0, c1, c2);
+                c0 = fmaf(t0r * v.al0, wgt, c0);
+                c1 = fmaf(t1r * v.al1, wgt, c1);
+                c2 = fmaf(t2r * v.al2, wgt, c2);
+                float boa, bob, boc, bda, bdb, bdc;
+                if (continue_path(f, v, ks, seg, t0r, t1r, t2r, boa, bob, boc, bda, bdb, bdc)) {
+                    COLD_SET_T(t0r, t1r, t2r);
+                    COLD_SET_C(c0, c1, c2);
+                    if (STATS) cnt[ST_BOUNCE]++;
+                    const bool go = march_begin<false, STATS, true>(f, boa, bob, boc, bda, bdb, bdc, m, cnt);
+                    hit = false; shadow = false;
+                    state = go ? PS_NEEDSEG : PS_ENDED;
+                } else {
+                    c_store(pq, e, c0, c1, c2);
+                    state = PS_IDLE;
+                }
+            }
+#else
             if (state == PS_ESCAPED) {
                 float e0, e1, e2;
                 if (escaped_radiance<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, e0, e1, e2, cnt)) {
@@ -2210,6 +2424,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                     state = PS_IDLE;
                 }
             }
+#endif
         }
         PPROF_T(13);
     }
