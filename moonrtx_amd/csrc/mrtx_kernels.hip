@@ -34,6 +34,10 @@
 #define MRTX_TRIAL_BATCH 1     // steps fetched together in the trial segment.  Round 4 (8 waves per SIMD, VALU issue 0.65): 1 step
 #endif                         // 16.20 ms against 16.34 with 2 -- the 64 continuation rays are incoherent, a speculated second step is
                                // mostly thrown away; the coherent marches keep MRTX_STEP_BATCH = 2 (1: 16.64 ms, 3: 16.68)
+#ifndef MRTX_ENV_PREFETCH
+#define MRTX_ENV_PREFETCH 0    // 1: render_kernel<MODE 2> fetches the environment texel of a continuation ray BEFORE its trial segment, so
+#endif                         // that the DRAM miss hides behind the march.  Bit-exact; measured on the star-map frame (gpurun_out/r4z): render
+                               // 17.28 ms against 17.06 -- the 19 % extra look-ups (rays that hit or march on) cost more than the hidden round: off
 #ifndef MRTX_TRIAL_SEGMENT
 #define MRTX_TRIAL_SEGMENT 1   // 0 = hand every continuation ray to path_kernel unmarched (A/B switch, see trace_sample)
 #endif
@@ -707,9 +711,8 @@ __device__ __forceinline__ void duff_basis(float na, float nb, float nc, float& 
 }
 
 // D7: nearest environment texel along a scene-frame direction
-template <bool STATS>
-__device__ __forceinline__ void env_lookup(const FrameC& f, float dx, float dy, float dz, float& e0, float& e1, float& e2,
-                                           uint32_t* cnt) {
+// ... in two halves, so that a caller can issue the fetch long before it needs the texel: the texel's index, and its decoding
+__device__ __forceinline__ int64_t env_texel_index(const FrameC& f, float dx, float dy, float dz) {
     float el, az;
     latlon(dx, dy, dz, fmaf(dy, dy, dx * dx), el, az);
     const float rowf = fmaf(el, CF(f)->bg_row_scale, CF(f)->bg_row_off);
@@ -718,11 +721,24 @@ __device__ __forceinline__ void env_lookup(const FrameC& f, float dx, float dy, 
     r = r < 0 ? 0 : (r > CF(f)->bg_h - 1 ? CF(f)->bg_h - 1 : r);
     if (c >= CF(f)->bg_w) c -= CF(f)->bg_w;
     if (c < 0) c = 0;
-    const uint32_t px = reinterpret_cast<const uint32_t*>(CF(f)->bg)[(int64_t)r * CF(f)->bg_w + c];
+    return (int64_t)r * CF(f)->bg_w + c;
+}
+__device__ __forceinline__ void env_decode(uint32_t px, float& e0, float& e1, float& e2) {
     e0 = (float)(px & 255u) * kInv255;
     e1 = (float)((px >> 8) & 255u) * kInv255;
     e2 = (float)((px >> 16) & 255u) * kInv255;
+}
+template <bool STATS>
+__device__ __forceinline__ void env_lookup(const FrameC& f, float dx, float dy, float dz, float& e0, float& e1, float& e2,
+                                           uint32_t* cnt) {
+    env_decode(reinterpret_cast<const uint32_t*>(CF(f)->bg)[env_texel_index(f, dx, dy, dz)], e0, e1, e2);
     if (STATS) cnt[ST_BG]++;
+}
+// moon-frame direction -> scene frame (the environment map is addressed in scene coordinates)
+__device__ __forceinline__ void to_scene_dir(const FrameC& f, float bda, float bdb, float bdc, float& ex, float& ey, float& ez) {
+    ex = fmaf(bdc, CF(f)->Mf[2][0], fmaf(bdb, CF(f)->Mf[1][0], bda * CF(f)->Mf[0][0]));
+    ey = fmaf(bdc, CF(f)->Mf[2][1], fmaf(bdb, CF(f)->Mf[1][1], bda * CF(f)->Mf[0][1]));
+    ez = fmaf(bdc, CF(f)->Mf[2][2], fmaf(bdb, CF(f)->Mf[1][2], bda * CF(f)->Mf[0][2]));
 }
 
 // surface point -> normal (central differences of D one texel either side of it) and albedo (D4)
@@ -863,9 +879,11 @@ __device__ __forceinline__ bool continue_path(const FrameC& f, const Vertex& v, 
 // disk bounces onto the Moon small through its radiance 2.0 and by parking it, moon_renderer.py:109-111, :757-760),
 // then the environment texel along its direction; adds throughput x radiance.  Moon frame, float32: distance of the
 // disk centre from the ray.
-template <bool STATS>
+// PRE: the caller fetched the environment texel of this direction already (`pre_px`; render_kernel<MODE 2> issues the fetch before the
+// trial segment so that its latency hides behind the march): same texel, same result, no load here
+template <bool STATS, bool PRE = false>
 __device__ __forceinline__ bool escaped_radiance(const FrameC& f, float boa, float bob, float boc, float bda, float bdb,
-                                                 float bdc, float& e0, float& e1, float& e2, uint32_t* cnt) {
+                                                 float bdc, float& e0, float& e1, float& e2, uint32_t* cnt, uint32_t pre_px = 0u) {
     if (CF(f)->sun_on) {
         const float sa = CF(f)->Sb[0] - boa, sb = CF(f)->Sb[1] - bob, sc = CF(f)->Sb[2] - boc;
         const float bq = fmaf(sc, bdc, fmaf(sb, bdb, sa * bda));
@@ -878,20 +896,24 @@ __device__ __forceinline__ bool escaped_radiance(const FrameC& f, float boa, flo
         }
     }
     if (CF(f)->bg) {   // environment radiance along its direction (scene frame)
-        const float ex = fmaf(bdc, CF(f)->Mf[2][0], fmaf(bdb, CF(f)->Mf[1][0], bda * CF(f)->Mf[0][0]));
-        const float ey = fmaf(bdc, CF(f)->Mf[2][1], fmaf(bdb, CF(f)->Mf[1][1], bda * CF(f)->Mf[0][1]));
-        const float ez = fmaf(bdc, CF(f)->Mf[2][2], fmaf(bdb, CF(f)->Mf[1][2], bda * CF(f)->Mf[0][2]));
-        env_lookup<STATS>(f, ex, ey, ez, e0, e1, e2, cnt);
+        if (PRE) {
+            env_decode(pre_px, e0, e1, e2);
+            if (STATS) cnt[ST_BG]++;
+        } else {
+            float ex, ey, ez;
+            to_scene_dir(f, bda, bdb, bdc, ex, ey, ez);
+            env_lookup<STATS>(f, ex, ey, ez, e0, e1, e2, cnt);
+        }
         return true;
     }
     return false;
 }
-template <bool STATS>
+template <bool STATS, bool PRE = false>
 __device__ __forceinline__ void escaped_path(const FrameC& f, float boa, float bob, float boc, float bda, float bdb,
                                              float bdc, float t0r, float t1r, float t2r, float& c0, float& c1,
-                                             float& c2, uint32_t* cnt) {
+                                             float& c2, uint32_t* cnt, uint32_t pre_px = 0u) {
     float e0, e1, e2;
-    if (escaped_radiance<STATS>(f, boa, bob, boc, bda, bdb, bdc, e0, e1, e2, cnt)) {
+    if (escaped_radiance<STATS, PRE>(f, boa, bob, boc, bda, bdb, bdc, e0, e1, e2, cnt, pre_px)) {
         c0 = fmaf(t0r, e0, c0); c1 = fmaf(t1r, e1, c1); c2 = fmaf(t2r, e2, c2);
     }
 }
@@ -1451,6 +1473,17 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 }
                 MarchState tm;
                 tm.rowA = o.row; tm.colA = o.col;
+                // With an environment map bound (the reference's default, moon_renderer.py:604-607) 84 % of the continuation rays
+                // end in this segment by leaving the Moon, and each then reads one texel of a 537 MB map -- a DRAM miss at the very
+                // end of the wave's life.  The texel depends on the ray's direction alone: its fetch is issued HERE and lands while
+                // the segment is marched (a wasted 4-byte fetch for the rays that hit or march on).
+                constexpr bool ENVPRE = MRTX_ENV_PREFETCH != 0;
+                uint32_t env_px = 0u;
+                if (ENVPRE && CF(f)->bg != nullptr) {          // wave-uniform
+                    float ex, ey, ez;
+                    to_scene_dir(f, o.da, o.db, o.dc, ex, ey, ez);
+                    env_px = reinterpret_cast<const uint32_t*>(CF(f)->bg)[env_texel_index(f, ex, ey, ez)];
+                }
                 if (PARK) {     // the radiance so far, the throughput and the key sit out the trial segment in LDS
                     park_put(park, 0, o.c0, o.c1, o.c2, o.t0);
                     park_put(park, 1, o.t1, o.t2, __uint_as_float(o.ks), 0.0f);
@@ -1477,7 +1510,8 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                     for (int i = 0; i < ST_N; i++) cnt[i] += tcnt[i];
                 }
                 if (!tgo && !thit) {
-                    escaped_path<STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, t0r, t1r, t2r, o.c0, o.c1, o.c2, cnt);
+                    if (ENVPRE) escaped_path<STATS, true>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, t0r, t1r, t2r, o.c0, o.c1, o.c2, cnt, env_px);
+                    else escaped_path<STATS>(f, o.oa, o.ob, o.oc, o.da, o.db, o.dc, t0r, t1r, t2r, o.c0, o.c1, o.c2, cnt);
                 } else {
                     o.path = true;
                     if (thit) {
