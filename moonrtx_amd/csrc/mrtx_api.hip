@@ -33,6 +33,9 @@ hipError_t mrtx_launch_pack(const float* accum, const float* hits, void* dst, in
 hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W, int H, int tw, int th,
                               int tiles_x, int n_tiles, int src_rank, int world, int slots, const int32_t* list, int shift,
                               int with_hits, hipStream_t st);
+hipError_t mrtx_launch_unpack_all(float* accum, float* hits, const void* const* srcs, int W, int H, int tw, int th, int tiles_x,
+                                  int n_tiles, int self, int world, int slots, const int32_t* list_all, int shift, int with_hits,
+                                  hipStream_t st);
 hipError_t mrtx_launch_zero_tiles(float* accum, float* hits, const int32_t* tiles, int n, int W, int H, int tw, int th,
                                   int tiles_x, int shift, hipStream_t st);
 hipError_t mrtx_launch_ldem(const int16_t* src, float* dst, int h, int w, int d, unsigned int* max_bits,
@@ -1399,13 +1402,22 @@ int mrtx_unpack_all(mrtx_ctx* c, const void* const* dev_srcs, int32_t n) {
     if (rc == MRTX_OK) rc = upload_layout(c);
     if (rc == MRTX_OK) rc = clear_stale_peer_tiles(c);
     if (rc != MRTX_OK) return rc;
-    for (int r = 0; r < n; r++) {
-        if (r == c->cfg.rank) continue;
-        if (!dev_srcs[r]) return fail(c, MRTX_E_INVALID, "missing shard of rank %d", r);
-        HIPCHK(c, mrtx_launch_unpack(c->accum, c->hits, dev_srcs[r], c->cfg.width, c->cfg.height, c->cfg.tile_w,
-                                     c->cfg.tile_h, c->tiles_x, c->n_tiles, r, c->cfg.world, c->act_slots,
-                                     layout_list(c, r), c->tile_shift, c->gather_hits ? 1 : 0, c->stream));
-        mark_peer_written(c, r);
+    for (int r = 0; r < n; r++)
+        if (r != c->cfg.rank && !dev_srcs[r]) return fail(c, MRTX_E_INVALID, "missing shard of rank %d", r);
+    if (n <= 16) {      // one launch for all peers (pointers by value in the kernel arguments)
+        HIPCHK(c, mrtx_launch_unpack_all(c->accum, c->hits, dev_srcs, c->cfg.width, c->cfg.height, c->cfg.tile_w, c->cfg.tile_h,
+                                         c->tiles_x, c->n_tiles, c->cfg.rank, c->cfg.world, c->act_slots,
+                                         c->act_on ? c->act_dev : nullptr, c->tile_shift, c->gather_hits ? 1 : 0, c->stream));
+        for (int r = 0; r < n; r++)
+            if (r != c->cfg.rank) mark_peer_written(c, r);
+    } else {
+        for (int r = 0; r < n; r++) {
+            if (r == c->cfg.rank) continue;
+            HIPCHK(c, mrtx_launch_unpack(c->accum, c->hits, dev_srcs[r], c->cfg.width, c->cfg.height, c->cfg.tile_w,
+                                         c->cfg.tile_h, c->tiles_x, c->n_tiles, r, c->cfg.world, c->act_slots,
+                                         layout_list(c, r), c->tile_shift, c->gather_hits ? 1 : 0, c->stream));
+            mark_peer_written(c, r);
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MRTX_OK;

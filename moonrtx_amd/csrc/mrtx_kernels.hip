@@ -412,6 +412,9 @@ __device__ __forceinline__ bool below_seg(const FrameC& f, const Seg& sg, float 
 #ifndef MRTX_STEP_BATCH
 #define MRTX_STEP_BATCH 2
 #endif
+#ifndef MRTX_SHADOW_BATCH
+#define MRTX_SHADOW_BATCH MRTX_STEP_BATCH     // the first vertex's shadow march in render_kernel<MODE 2> (A/B: 1 / 2 / 3)
+#endif
 #ifndef MRTX_STEP_BATCH_BOUNCE
 #define MRTX_STEP_BATCH_BOUNCE 1
 #endif
@@ -1417,7 +1420,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 MarchState ms;
                 ms.rowA = org_row; ms.colA = org_col;
                 bool sgo = march_begin_at<false, STATS, false, true>(f, oa, ob, oc, wa, wb, wc, ms, cnt, org_cell);
-                while (sgo) march_segment<WIDE, false, STATS, BATCH>(f, ms, 0.0f, ssg, sgo, occluded, sk_occ, cnt);
+                while (sgo) march_segment<WIDE, false, STATS, MRTX_SHADOW_BATCH>(f, ms, 0.0f, ssg, sgo, occluded, sk_occ, cnt);
 #else
                 occluded = march<WIDE, false, STATS, BATCH>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt);
 #endif
@@ -1839,7 +1842,6 @@ enum { PS_IDLE = 0, PS_NEEDSEG, PS_STEP, PS_BISECT, PS_ENDED, PS_HITWAIT, PS_SHA
 #endif
 template <bool STATS>
 __device__ __forceinline__ uint32_t step_mask(const FrameC& f, const MarchState& m, const Seg& sg, uint32_t todo, uint32_t* cnt) {
-    typedef const __attribute__((address_space(1))) float* GFloat;
     const float* m2 = CF(f)->mip2;
     const int pitch = CF(f)->m2_pitch, sh = CF(f)->m2_shift, mh = CF(f)->m2_h, mw = CF(f)->m2_w;
     uint32_t rem = todo, keep = 0u;
@@ -1945,7 +1947,9 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
     MarchState m;
     Seg sg;
     int j = 1;                    // next step of the current segment (STEP lanes)
-    uint32_t todo = 0u;           // MRTX_PATH_MIP2: the steps of the current segment still to be evaluated, bit jj - 1 for step jj >= j
+#if MRTX_PATH_MIP2
+    uint32_t todo = 0u;           // the steps of the current segment still to be evaluated, bit jj - 1 for step jj >= j
+#endif
     float sk_hit = 0.0f;
 #if MRTX_PATH_PARK
     float wgt = 0.0f;
@@ -2649,6 +2653,32 @@ __global__ void unpack_shard_kernel(float4* __restrict__ accum, float4* __restri
     }
 }
 
+// ... every peer's shard in ONE launch (the root of an 8-GPU job has seven to scatter, 6 MB each: seven launches are ~50 us of gaps
+// in a 3.3 ms step).  The source pointers travel by value in the kernel arguments (no upload); list_all = world x slots tile lists
+// (active layout) or null.
+struct UnpackSrcs { const float4* p[16]; };
+__global__ void unpack_all_kernel(float4* __restrict__ accum, float4* __restrict__ hits, const UnpackSrcs srcs, int W, int H, int tile_w,
+                                  int tile_h, int tiles_x, int n_tiles, int self, int world, int slots,
+                                  const int32_t* __restrict__ list_all, int shift, int with_hits) {
+    const int tile_px = tile_w * tile_h;
+    const int64_t per = (int64_t)slots * tile_px, total = per * world;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int src_rank = (int)(i / per);
+        if (src_rank == self) continue;
+        const int64_t k = i - (int64_t)src_rank * per;
+        const int slot = (int)(k / tile_px), r = (int)(k % tile_px);
+        const int lt = list_all ? list_all[(int64_t)src_rank * slots + slot] : slot;
+        const int t = lt * world + src_rank;
+        if (lt < 0 || t >= n_tiles) continue;
+        int tx, ty;
+        mrtx_tile_xy(t, tiles_x, shift, tx, ty);
+        const int x = tx * tile_w + r % tile_w, y = ty * tile_h + r / tile_w;
+        const float4* src = srcs.p[src_rank];
+        const int64_t o = (int64_t)slot * (with_hits ? 2 : 1) * tile_px + r;
+        if (x < W && y < H) { accum[(int64_t)y * W + x] = src[o]; if (with_hits) hits[(int64_t)y * W + x] = src[o + tile_px]; }
+    }
+}
+
 // rank 0, active layout: tiles of other ranks that held data of an earlier view and are sky in this one
 __global__ void zero_tiles_kernel(float4* __restrict__ accum, float4* __restrict__ hits, const int32_t* __restrict__ tiles,
                                   int n, int W, int H, int tile_w, int tile_h, int tiles_x, int shift) {
@@ -3137,6 +3167,18 @@ hipError_t mrtx_launch_unpack(float* accum, float* hits, const void* src, int W,
     hipLaunchKernelGGL(mrtx::unpack_shard_kernel, dim3(grid_for((int64_t)slots * tw * th)), dim3(256), 0, st,
                        reinterpret_cast<float4*>(accum), reinterpret_cast<float4*>(hits),
                        reinterpret_cast<const float4*>(src), W, H, tw, th, tiles_x, n_tiles, src_rank, world, slots, list, shift, with_hits);
+    return hipGetLastError();
+}
+hipError_t mrtx_launch_unpack_all(float* accum, float* hits, const void* const* srcs, int W, int H, int tw, int th, int tiles_x,
+                                  int n_tiles, int self, int world, int slots, const int32_t* list_all, int shift, int with_hits,
+                                  hipStream_t st) {
+    if (slots <= 0 || world < 2) return hipSuccess;
+    if (world > 16) return hipErrorInvalidValue;
+    mrtx::UnpackSrcs tab;
+    for (int r = 0; r < 16; r++) tab.p[r] = r < world ? reinterpret_cast<const float4*>(srcs[r]) : nullptr;
+    hipLaunchKernelGGL(mrtx::unpack_all_kernel, dim3(grid_for((int64_t)world * slots * tw * th)), dim3(256), 0, st,
+                       reinterpret_cast<float4*>(accum), reinterpret_cast<float4*>(hits), tab, W, H, tw, th, tiles_x, n_tiles, self, world,
+                       slots, list_all, shift, with_hits);
     return hipGetLastError();
 }
 hipError_t mrtx_launch_zero_tiles(float* accum, float* hits, const int32_t* tiles, int n, int W, int H, int tw, int th,
