@@ -509,7 +509,10 @@ def main():
             util = v["hbm_bytes"] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if v.get("hbm_bytes") and v.get("avg_ms") else None
             lim = None
             if util is not None:
-                lim = "hbm" if util >= 0.6 else ("valu+latency" if (v.get("valu_issue_frac") or 0) >= 0.3 else "latency")
+                # "memory-system": traffic beyond the L2s (Infinity-Cache hits included) >= 0.6 of the HBM peak.  Round 4 showed for
+                # path_kernel that this does NOT mean "bound by bytes" (halving them left its time unchanged): dependent memory rounds
+                # against a memory system close to saturation -- see the kernel's limited_by_note
+                lim = "memory-system" if util >= 0.6 else ("valu+latency" if (v.get("valu_issue_frac") or 0) >= 0.3 else "latency")
             return {"hbm_bytes": int(v["hbm_bytes"]) if v.get("hbm_bytes") else None, "hbm_utilisation": None if util is None else round(util, 4),
                     "hbm_bytes_note": "FETCH_SIZE / WRITE_SIZE = traffic leaving the L2s: it INCLUDES what the 256 MB Infinity Cache serves (MI355X_MICROARCH.md), so 'hbm' here means the memory side of the L2, an upper bound on DRAM traffic",
                     "valu_issue_frac": v.get("valu_issue_frac"), "lanes_per_valu_inst": v.get("lanes_per_valu"), "l2_hit": v.get("l2_hit"),
@@ -524,8 +527,9 @@ def main():
                 "kernel": dom, "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": int(dom_bytes),
                 "limited_by": (measured(pk) or {}).get("limited_by"),
                 "limiter": "`bound` names the roofline the fraction is priced against (the HBM read roofline BASELINE.json asks for); what the PMC "
-                           "counters say limits each kernel is `limited_by` (here and per kernel under `kernels`): hbm = measured traffic beyond the L2s "
-                           "(FETCH_SIZE: Infinity-Cache hits included, so an upper bound on DRAM traffic) >= 0.6 of the HBM peak, valu+latency = VALU "
+                           "counters say limits each kernel is `limited_by` (here and per kernel under `kernels`): memory-system = measured traffic beyond the L2s "
+                           "(FETCH_SIZE: Infinity-Cache hits included, so an upper bound on DRAM traffic) >= 0.6 of the HBM peak -- which for path_kernel "
+                           "is dependent memory rounds against a nearly saturated memory system, not bytes (limited_by_note) --, valu+latency = VALU "
                            "issue >= 0.3 with that traffic far from the peak (VALU issue + dependent-load rounds)",
                 "valu_issue_frac": None if pk is None else pk.get("valu_issue_frac"),
                 "hbm_utilisation": None if pk is None else round(pk["hbm_bytes"] / (pk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
