@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Digest a tools/profile_bench.sh output directory into tracked files: profiles/<tag>_kernel_stats.csv, profiles/<tag>_summary.md
 and profiles/traffic_latest.json (what bench.py quotes as roofline.traffic / valu_issue_frac / hbm_utilisation -- accepted there
-only while its `source_hash` equals the hash of the kernel sources bench.py runs).  usage: summarise_profile.py <dir> <tag>"""
+only while its `source_hash` equals the hash of the kernel sources bench.py runs).  usage: summarise_profile.py <dir> <tag> [--no-latest]
+(--no-latest: a profile of another view, e.g. `profile_bench.sh <tag> --zoom 0.7`: traffic_latest.json stays the headline's)"""
 import csv, glob, collections, os, shutil, sys, json
 
 src, tag = sys.argv[1], sys.argv[2]
@@ -102,5 +103,6 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
             k["valu_issue_frac"] = round(m["SQ_INSTS_VALU"] * 2 / (1024 * cyc), 4)
             o.write(f"- kernel cycles (GRBM_GUI_ACTIVE/8) = {cyc:.4g}; VALU issue fraction = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x cycles) = {k['valu_issue_frac']:.3f}\n")
         out["kernels"][s] = k
-json.dump(out, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+if "--no-latest" not in sys.argv:
+    json.dump(out, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())
