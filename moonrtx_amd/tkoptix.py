@@ -17,7 +17,8 @@ What differs, by design: there is no Tk window here (no Tk on a headless GPU nod
 are None and the `_gui_*` handler slots are plain attributes a viewer may call.  One launch adds
 `spp_per_launch` samples per pixel (a whole 64-lane wavefront per pixel) instead of one:
 max_accumulation_frames=64 is ONE launch, max_accumulation_frames=1 (the interactive preview,
-moon_renderer.py:457-488) is a 1-spp launch.  The NVENC encoder is refused explicitly (no AMD analogue here).
+moon_renderer.py:457-488) is a 1-spp launch.  The encoder (NVENC H.264 in the reference) writes a Motion-JPEG AVI instead
+(moonrtx_amd/video.py): same encoder_* calls, one frame per finished cycle.
 """
 import os
 import threading
@@ -144,6 +145,9 @@ class TkOptiX:
         self._frames_done = 0
         self._image = np.zeros((self._height, self._width, 4), np.uint8)   # reused for every read-back
         self._warned = set()
+        self._encoder_cfg = None
+        self._encoder = None
+        self.encoder_file = None
         if start_now:
             self.start()
 
@@ -472,6 +476,7 @@ class TkOptiX:
                 with self._padlock:
                     if self._on_rt_completed is not None:
                         self._on_rt_completed(self)
+                    self._encode_cycle()
                     cb = self._accum_done_cb
                     if cb is not None and not self._dirty:
                         cb(self)                                 # padlock held (renderer_video.py:276-281)
@@ -500,6 +505,7 @@ class TkOptiX:
                 if self._on_launch_finished is not None:
                     self._on_launch_finished(self)
                 if done:
+                    self._encode_cycle()
                     return self._image
 
     def set_accum_done_cb(self, cb):
@@ -518,6 +524,8 @@ class TkOptiX:
         if self._thread is not None and self._thread is not threading.current_thread():
             self._thread.join(timeout=10.0)
         with self._padlock:
+            if self._encoder is not None:
+                self._encoder.close()
             if self._rt is not None:
                 self._rt.close()
                 self._rt = None
@@ -590,14 +598,56 @@ class TkOptiX:
         self.setup_light("sun", pos=list(s.light_pos), color=s.light_radiance, radius=s.light_radius, in_geometry=False)
         self.set_data("sun_disk", geom="ParticleSet", mat="flat", pos=[list(s.sun_pos)], r=s.sun_radius, c=s.sun_radiance)
 
-    # ------------------------------------------------------------------ encoder (NVENC in the reference)
-    def encoder_create(self, *a, **k):
-        raise NotImplementedError("video encoding is outside this backend (renderer_video.py:219-260 uses NVENC)")
+    # ------------------------------------------------------------------ encoder (NVENC H.264 in the reference)
+    # PlotOptiX captures one video frame per finished accumulation cycle between encoder_start() and the frame limit /
+    # encoder_stop() (renderer_video.py:219-260, :276-340).  No NVENC and no FFmpeg here: the frames go into a Motion-JPEG AVI
+    # (moonrtx_amd/video.py).  A requested name that does not end in .avi gets that suffix appended (`encoder_file` says where
+    # the frames went): an .mp4 name on a RIFF file would mislead every player.
+    def encoder_create(self, fps, bitrate=2, idrrate=None, profile=None, preset=None):
+        """encoder_create(fps=, bitrate=[Mbit/s]) -- renderer_video.py:222.  idrrate / profile / preset are H.264 notions; accepted, unused."""
+        if not fps or fps <= 0 or bitrate <= 0:
+            raise ValueError("fps and bitrate must be positive")
+        with self._padlock:
+            self._encoder_cfg = (fps, float(bitrate))
 
-    encoder_start = encoder_stop = encoder_create
+    def encoder_start(self, out_name, n_frames=0):
+        """encoder_start(filename, n_frames) -- renderer_video.py:241: capture starts with the NEXT finished cycle; after n_frames
+        frames (0 = until encoder_stop) the file closes by itself."""
+        from .video import MjpegAviWriter
+        with self._padlock:
+            if self._encoder_cfg is None:
+                raise RuntimeError("encoder_create() first")
+            if self._encoder is not None and self._encoder.open:
+                raise RuntimeError("encoder is already running")
+            name = out_name if str(out_name).lower().endswith(".avi") else str(out_name) + ".avi"
+            fps, mbps = self._encoder_cfg
+            self._encoder = MjpegAviWriter(name, self._width, self._height, fps, mbps, n_frames=int(n_frames))
+            self.encoder_file = name
+
+    def encoder_stop(self):
+        """encoder_stop() -- renderer_video.py:340."""
+        with self._padlock:
+            if self._encoder is not None:
+                self._encoder.close()
 
     def encoder_is_open(self):
-        return False
+        """renderer_video.py:252, :290: True from encoder_start until the frame limit or encoder_stop."""
+        enc = self._encoder
+        return enc is not None and enc.open
+
+    def encoded_frames(self):
+        enc = self._encoder
+        return enc.frames if enc is not None else 0
+
+    def encoding_frames(self):
+        enc = self._encoder
+        return enc.limit if enc is not None else 0
+
+    def _encode_cycle(self):
+        """Called with the padlock held when a cycle has converged, before the accum-done callback moves the scene on."""
+        enc = self._encoder
+        if enc is not None and enc.open and not self._dirty:
+            enc.add_frame(self._image)
 
     def _warn_once(self, key, msg):
         if key not in self._warned:

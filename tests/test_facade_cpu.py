@@ -186,9 +186,9 @@ def test_unsupported_pieces_are_explicit():
     assert np.allclose(be.last("set_capsules")[1][0][0, :3], [0, -20.5, 0])
     rt.delete_geometry("labels"); rt.delete_geometry("grid")
     assert len(be.last("set_capsules")[1][0]) == 0
-    with pytest.raises(NotImplementedError):
-        rt.encoder_create(fps=30, bitrate=8)
     assert rt.encoder_is_open() is False
+    with pytest.raises(RuntimeError):
+        rt.encoder_start("x.avi", 3)                                 # encoder_create first
     with pytest.raises(ValueError):
         rt.set_param(bogus=1)
     with pytest.raises(ValueError):
@@ -316,3 +316,80 @@ def test_save_image_16_bits_after_changing_the_cycle_length(tmp_path):
     pushed = be.last("set_params")[2]
     assert pushed == {"tonemap_exposure": 0.9, "tonemap_gamma": 1.8}
     rt.close()
+
+
+def test_video_export_drives_the_encoder_like_renderer_video(tmp_path):
+    """renderer_video.py:219-340: encoder_create, encoder_start(filename, n), one frame per finished accumulation cycle, the
+    accum-done callback moving the scene on, the encoder closing by itself at the frame limit."""
+    from moonrtx_amd.video import read_avi_frames
+    rt, be, _ = make()
+    drive_like_init_renderer(rt, np.zeros((8, 16), np.float32), np.zeros((4, 8, 4), np.uint8))
+    rt.encoder_create(fps=25, bitrate=16)
+    name = str(tmp_path / "moon.mp4")
+    rt.encoder_start(name, 3)
+    assert rt.encoder_is_open() and rt.encoder_file == name + ".avi" and rt.encoding_frames() == 3
+    with pytest.raises(RuntimeError):
+        rt.encoder_start(name, 3)                                    # already running
+    seen = []
+
+    def accum_done(r):
+        seen.append(r.encoded_frames())                              # the frame of this cycle is already captured
+        if len(seen) < 5:
+            r.update_light("sun", pos=[100.0 * len(seen), 0.0, 0.0])
+            r.refresh_scene()
+
+    rt.set_accum_done_cb(accum_done)
+    rt.start()
+    t0 = time.time()
+    while len(seen) < 5 and time.time() - t0 < 20.0:
+        time.sleep(0.01)
+    rt.set_accum_done_cb(None)
+    assert seen == [1, 2, 3, 3, 3]                                   # closed by itself after three frames
+    assert not rt.encoder_is_open() and rt.encoded_frames() == 3
+    rt.encoder_stop()                                                # harmless after the automatic close (renderer_video.py:339-340)
+    rt.close()
+    info, frames = read_avi_frames(name + ".avi")
+    assert (info["width"], info["height"], info["total_frames"], info["length"]) == (16, 8, 3, 3)
+    assert info["handler"] == b"MJPG" and info["rate"] / info["scale"] == 25 and info["usec_per_frame"] == 40000
+    assert info["riff_size"] == info["file_size"] - 8 and len(frames) == 3
+    assert all(f[:2] == b"\xff\xd8" and f[-2:] == b"\xff\xd9" for f in frames)
+
+
+def test_mjpeg_avi_round_trip_and_rate_control(tmp_path):
+    import io
+    from PIL import Image
+    from moonrtx_amd.video import MjpegAviWriter, read_avi_frames, pick_quality
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:96, 0:160]
+    base = (96 + 80 * np.sin(xx / 17.0) * np.cos(yy / 11.0)).astype(np.float32)
+    imgs = []
+    for k in range(4):
+        rgb = np.stack([base + 10 * k, base * 0.9, base * 0.8 + 5 * k], -1) + rng.normal(0, 2.0, (96, 160, 3))
+        imgs.append(np.clip(rgb, 0, 255).astype(np.uint8))
+    path = str(tmp_path / "t.avi")
+    w = MjpegAviWriter(path, 160, 96, fps=29.97, bitrate_mbps=50.0)          # ample budget: top quality
+    for im in imgs[:3]:
+        w.add_frame(im)
+    w.add_frame(np.dstack([imgs[3], np.full((96, 160), 255, np.uint8)]))       # RGBA frames as the facade hands them over
+    assert w.quality == 95 and w.frames == 4 and w.open
+    w.close(); w.close()
+    with pytest.raises(RuntimeError):
+        w.add_frame(imgs[0])
+    info, frames = read_avi_frames(path)
+    assert info["total_frames"] == 4 and (info["rate"], info["scale"]) == (29970, 1000) and info["usec_per_frame"] == 33367
+    for im, jp in zip(imgs, frames):
+        dec = np.asarray(Image.open(io.BytesIO(jp)).convert("RGB"), np.float32)
+        mse = np.mean((dec - im.astype(np.float32)) ** 2)
+        assert 10 * np.log10(255.0 ** 2 / mse) > 30.0                            # the frame that went in
+    # a tight budget lowers the quality, but never below the floor
+    big = len(frames[0])
+    q = pick_quality(imgs[0], big // 2, q_min=40, q_max=95)
+    assert 40 <= q < 95
+    assert pick_quality(imgs[0], 10, q_min=70, q_max=95) == 70
+    with pytest.raises(ValueError):
+        MjpegAviWriter(str(tmp_path / "bad.avi"), 160, 96, fps=0)
+    w2 = MjpegAviWriter(str(tmp_path / "shape.avi"), 160, 96, fps=30)
+    with pytest.raises(ValueError):
+        w2.add_frame(np.zeros((96, 161, 3), np.uint8))
+    w2.close()
+    assert read_avi_frames(str(tmp_path / "shape.avi"))[0]["total_frames"] == 0

@@ -89,3 +89,51 @@ def test_rendered_phase_matches_the_ephemeris(native_lib):
             # (moon_renderer.py:522-544: the camera distance follows the topocentric distance)
             scale = math.asin(1737.4 / e.distance) / math.asin(1737.4 / 384400.0)
             assert abs(disc.sum() / (math.pi * (0.45 * H * scale) ** 2) - 1.0) < 0.02, (days, disc.sum(), scale)
+
+
+def test_video_export_on_gpu_holds_the_rendered_frames(native_lib, tmp_path):
+    """renderer_video.py:219-340 on the HIP backend: three converged cycles with the Sun moving in between, each captured into the
+    Motion-JPEG AVI before the accum-done callback moves the scene on; the decoded frames are the cycles' RGBA8 images."""
+    import io
+    import threading
+    from PIL import Image
+    from moonrtx_amd.video import read_avi_frames
+    W, H = 128, 96
+    dem = synth_np.dem(180, 360, seed=2, craters=20)
+    rt = TkOptiX(width=W, height=H)
+    drive_like_init_renderer(rt, dem, synth_np.colour_map(90, 180))
+    s = sc.named_scene("S1", W, H, spp_per_launch=64)
+    with rt._padlock:
+        rt.update_camera("cam1", eye=list(s.eye))
+        rt.update_data("moon", u=s.u, v=s.v)
+        rt.update_light("sun", pos=list(s.light_pos), radius=s.light_radius)
+    rt.encoder_create(fps=30, bitrate=60)
+    rt.encoder_start(str(tmp_path / "phase.avi"), 3)
+    shots, finished = [], threading.Event()
+    lp = np.array(s.light_pos, float)
+
+    def accum_done(r):
+        shots.append(r.get_image().copy())
+        if len(shots) < 3:
+            k = len(shots)
+            c, sn = np.cos(0.6 * k), np.sin(0.6 * k)
+            r.update_light("sun", pos=[c * lp[0] - sn * lp[1], sn * lp[0] + c * lp[1], lp[2]])
+            r.refresh_scene()
+        else:
+            finished.set()
+
+    rt.set_accum_done_cb(accum_done)
+    rt.start()
+    assert finished.wait(60.0)
+    assert not rt.encoder_is_open() and rt.encoded_frames() == 3
+    rt.close()
+    info, frames = read_avi_frames(str(tmp_path / "phase.avi"))
+    assert (info["width"], info["height"], info["total_frames"]) == (W, H, 3)
+    means = []
+    for shot, jp in zip(shots, frames):
+        dec = np.asarray(Image.open(io.BytesIO(jp)).convert("RGB"), np.float32)
+        ref = shot[..., :3].astype(np.float32)
+        assert ref.max() > 50
+        assert 10 * np.log10(255.0 ** 2 / max(1e-9, np.mean((dec - ref) ** 2))) > 32.0
+        means.append(ref.mean())
+    assert len({round(m, 2) for m in means}) == 3          # the Sun moved: three different frames
