@@ -64,7 +64,8 @@ struct mrtx_ctx {
     float* path_rec = nullptr; uint32_t* path_meta = nullptr; uint8_t* path_npaths = nullptr; uint64_t path_cap = 0;
     uint32_t* path_ctr = nullptr;        // 8 x 16 work counters of path_kernel
     unsigned long long* wd_host = nullptr;   // pinned: path_kernel's watchdog word
-    uint64_t path_budget_bytes = 24ull << 30;   // hand-over buffers: frames that need more are rendered in sub-parts (MOONRT_PATH_MAX_GB)
+    uint64_t path_budget_bytes = 64ull << 30;   // hand-over buffers: frames that need more are rendered in sub-parts (MOONRT_PATH_MAX_GB).  Sized for 288 GB of HBM:
+                                                // a 4K frame with every pixel on the Moon (34 GB) stays ONE part -- 38.9 ms against 39.2 in two parts of 24 GB
     bool path_budget_env = false;               // the budget was given explicitly: take it as it is (else: at most half of the free memory)
     int path_nsub = 4, path_grp_log2 = 3;   // measured at cfg3: (0,1) 37 ms, (1,1) 20.5, (1,4) 16.1, (2,4) 16.3, (3,4) 16.6
     int path_waves[4] = {0, 0, 0, 0};    // persistent waves of path_kernel<stats, wide>, 0 = not asked yet

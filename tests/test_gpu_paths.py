@@ -91,7 +91,7 @@ def test_path_queue_with_overlay_tubes(native_lib, rough):
 
 
 def test_hand_over_buffers_are_bounded_by_rendering_in_sub_parts(native_lib, rough, monkeypatch):
-    """A frame whose hand-over records would exceed the budget (MOONRT_PATH_MAX_GB; 24 GB by default, e.g. a cfg4 frame with
+    """A frame whose hand-over records would exceed the budget (MOONRT_PATH_MAX_GB; 64 GB by default, e.g. a cfg4 frame with
     every pixel on the Moon needs 129 GB) is rendered in sub-parts of its tile list through the same buffers -- same frame."""
     s = named_scene("S1", 160, 128, spp_per_launch=64)
     s.path_seg_min, s.path_seg_max = 2, 4
