@@ -147,6 +147,8 @@ class TkOptiX:
         self._warned = set()
         self._encoder_cfg = None
         self._encoder = None
+        self._encode_ring = []            # spare read-back buffers while an encoder holds earlier frames
+        self._image_lent = False
         self.encoder_file = None
         if start_now:
             self.start()
@@ -455,6 +457,10 @@ class TkOptiX:
         return self._frames_done >= launches
 
     def _read_image(self):
+        if self._image_lent:             # an encoder thread is still reading that buffer: this read-back goes to the next one of the ring
+            self._encode_ring.append(self._image)
+            self._image = self._encode_ring.pop(0)
+            self._image_lent = False
         try:
             got = self._rt.read_rgba8(out=self._image)
         except TypeError:                # a backend without the `out` parameter
@@ -647,7 +653,20 @@ class TkOptiX:
         """Called with the padlock held when a cycle has converged, before the accum-done callback moves the scene on."""
         enc = self._encoder
         if enc is not None and enc.open and not self._dirty:
-            enc.add_frame(self._image)
+            try:
+                # the JPEG coding runs on the writer's own threads, on THIS array: the next read-backs go to other buffers of a
+                # small ring (a frame is handed over, not copied)
+                ring = self._encode_ring
+                while len(ring) < enc.max_pending + 3:
+                    ring.append(np.zeros_like(self._image))
+                enc.add_frame(self._image, copy=False)
+                self._image_lent = True            # still the frame get_image() shows; replaced at the next read-back
+            except Exception as e:                 # PlotOptiX logs encoder failures and closes (renderer_video.py:243-251, :288-292)
+                self._warn_once("encoder", f"video encoder stopped after {enc.frames} frames: {e}")
+                try:
+                    enc.close()
+                except Exception:
+                    pass
 
     def _warn_once(self, key, msg):
         if key not in self._warned:

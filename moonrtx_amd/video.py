@@ -23,8 +23,13 @@ def _jpeg(rgb, quality):
         from PIL import Image
     except ImportError as e:                                   # pragma: no cover - Pillow is part of the image
         raise RuntimeError("video export needs Pillow for the JPEG coding (no NVENC / FFmpeg on this backend)") from e
+    h, w, ch = rgb.shape
+    if ch == 4:       # the facade's RGBA8 image as it is: Pillow drops the fourth byte in C (a strided numpy copy costs 3x a frame's coding)
+        im = Image.frombuffer("RGBX", (w, h), rgb, "raw", "RGBX", 0, 1).convert("RGB")
+    else:
+        im = Image.frombuffer("RGB", (w, h), rgb, "raw", "RGB", 0, 1)
     buf = io.BytesIO()
-    Image.fromarray(rgb, "RGB").save(buf, format="JPEG", quality=int(quality), subsampling="4:2:0", optimize=False)
+    im.save(buf, format="JPEG", quality=int(quality), subsampling="4:2:0", optimize=False)
     return buf.getvalue()
 
 
@@ -49,7 +54,10 @@ class MjpegAviWriter:
     """AVI 1.0, one `vids`/`MJPG` stream.  add_frame(rgb_or_rgba uint8 [H, W, 3|4]) appends; close() patches the headers and writes
     the index.  `n_frames` > 0 closes the file by itself after that many frames (PlotOptiX's encoder_start contract)."""
 
-    def __init__(self, path, width, height, fps, bitrate_mbps=16.0, n_frames=0, q_min=None, q_max=95):
+    def __init__(self, path, width, height, fps, bitrate_mbps=16.0, n_frames=0, q_min=None, q_max=95, workers=None):
+        """`workers` JPEG coders run beside the caller (Pillow releases the GIL while it codes; default MOONRT_MJPEG_WORKERS or 3;
+        0 = code inside add_frame): a 4K frame takes ~30 ms to code against ~21 ms to render at 64 spp, so add_frame only copies
+        the RGB planes and hands them over; chunks are written in frame order, at most 2 x workers frames are in flight."""
         if width <= 0 or height <= 0 or fps <= 0:
             raise ValueError("width, height and fps must be positive")
         self.path, self.width, self.height = path, int(width), int(height)
@@ -65,6 +73,15 @@ class MjpegAviWriter:
         self._write_headers(0)
         self.movi_at = self.f.tell() - 4   # position of the 'movi' fourcc
         self.open = True
+        self.submitted = 0
+        self.pending = []                  # futures of frames not yet written, in frame order
+        n_workers = int(os.environ.get("MOONRT_MJPEG_WORKERS", "3")) if workers is None else int(workers)
+        self.pool = None
+        self.max_pending = 0
+        if n_workers > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=n_workers, thread_name_prefix="moonrt-mjpeg")
+            self.max_pending = 2 * n_workers
 
     # ---- layout: RIFF('AVI ' LIST('hdrl' avih LIST('strl' strh strf)) LIST('movi' 00dc...) idx1)
     def _write_headers(self, frames, riff_size=0, movi_size=4):
@@ -81,34 +98,60 @@ class MjpegAviWriter:
         self.f.write(b"LIST" + struct.pack("<I", len(hdrl)) + hdrl)
         self.f.write(b"LIST" + struct.pack("<I", movi_size) + b"movi")
 
-    def add_frame(self, image):
+    def add_frame(self, image, copy=True):
+        """`copy=False`: the caller hands the array over and does not touch it until max_pending + 1 further frames have been added
+        (the facade rotates its read-back buffers instead of copying 33 MB per 4K frame)."""
         if not self.open:
             raise RuntimeError("encoder is closed")
         a = np.asarray(image)
         if a.dtype != np.uint8 or a.ndim != 3 or a.shape[0] != self.height or a.shape[1] != self.width or a.shape[2] not in (3, 4):
             raise ValueError(f"frame must be uint8 [{self.height}, {self.width}, 3|4], got {a.dtype} {a.shape}")
-        rgb = np.ascontiguousarray(a[:, :, :3])
+        rgb = a.copy() if (copy or not a.flags.c_contiguous) else a
         if self.quality is None:
             self.quality = pick_quality(rgb, self.budget, self.q_min, self.q_max)
-        data = _jpeg(rgb, self.quality)
+        self.submitted += 1
+        if self.pool is None:
+            self._write_chunk(_jpeg(rgb, self.quality))
+        else:
+            self.pending.append(self.pool.submit(_jpeg, rgb, self.quality))
+            self._drain(block_above=self.max_pending)
+        if self.limit > 0 and self.submitted >= self.limit:
+            self.close()
+
+    def _write_chunk(self, data):
         pad = len(data) & 1
         if self.f.tell() + 8 + len(data) + pad + 16 * (len(self.index) + 2) > MAX_RIFF:
-            self.close()
+            for fut in self.pending:
+                fut.cancel()
+            self.pending = []
+            self._finish()
             raise RuntimeError("AVI file would exceed 4 GiB: closed after %d frames" % len(self.index))
         self.index.append((self.f.tell() - self.movi_at, len(data)))
         self.f.write(b"00dc" + struct.pack("<I", len(data)) + data + b"\0" * pad)
         self.max_chunk = max(self.max_chunk, len(data))
-        if self.limit > 0 and len(self.index) >= self.limit:
-            self.close()
+
+    def _drain(self, block_above=0):
+        """Write the coded frames at the head of the queue; wait while more than `block_above` are in flight."""
+        while self.pending and (self.pending[0].done() or len(self.pending) > block_above):
+            self._write_chunk(self.pending.pop(0).result())
 
     @property
     def frames(self):
-        return len(self.index)
+        """Frames accepted so far (PlotOptiX's encoded_frames); all of them are in the file once close() has returned."""
+        return self.submitted
 
     def close(self):
         if not self.open:
             return
+        self._drain(block_above=0)
+        self._finish()
+
+    def _finish(self):
+        if not self.open:
+            return
         self.open = False
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
         end_movi = self.f.tell()
         idx = b"".join(struct.pack("<4sIII", b"00dc", 0x10, off, size) for off, size in self.index)
         self.f.write(b"idx1" + struct.pack("<I", len(idx)) + idx)

@@ -361,13 +361,13 @@ def test_mjpeg_avi_round_trip_and_rate_control(tmp_path):
     from moonrtx_amd.video import MjpegAviWriter, read_avi_frames, pick_quality
     rng = np.random.default_rng(5)
     yy, xx = np.mgrid[0:96, 0:160]
-    base = (96 + 80 * np.sin(xx / 17.0) * np.cos(yy / 11.0)).astype(np.float32)
+    base = (60 + 50 * np.sin(xx / 17.0) * np.cos(yy / 11.0)).astype(np.float32)
     imgs = []
-    for k in range(4):
-        rgb = np.stack([base + 10 * k, base * 0.9, base * 0.8 + 5 * k], -1) + rng.normal(0, 2.0, (96, 160, 3))
+    for k in range(4):                                                          # 40 grey levels apart: a swapped pair would show
+        rgb = np.stack([base + 40 * k, base * 0.9 + 40 * k, base * 0.8 + 40 * k], -1) + rng.normal(0, 2.0, (96, 160, 3))
         imgs.append(np.clip(rgb, 0, 255).astype(np.uint8))
     path = str(tmp_path / "t.avi")
-    w = MjpegAviWriter(path, 160, 96, fps=29.97, bitrate_mbps=50.0)          # ample budget: top quality
+    w = MjpegAviWriter(path, 160, 96, fps=29.97, bitrate_mbps=50.0)          # ample budget: top quality; 3 coder threads
     for im in imgs[:3]:
         w.add_frame(im)
     w.add_frame(np.dstack([imgs[3], np.full((96, 160), 255, np.uint8)]))       # RGBA frames as the facade hands them over
@@ -381,6 +381,19 @@ def test_mjpeg_avi_round_trip_and_rate_control(tmp_path):
         dec = np.asarray(Image.open(io.BytesIO(jp)).convert("RGB"), np.float32)
         mse = np.mean((dec - im.astype(np.float32)) ** 2)
         assert 10 * np.log10(255.0 ** 2 / mse) > 30.0                            # the frame that went in
+    # coded inside add_frame (workers=0): the same bytes as the coder threads wrote, in the same order
+    w0 = MjpegAviWriter(str(tmp_path / "t0.avi"), 160, 96, fps=29.97, bitrate_mbps=50.0, n_frames=4, workers=0)
+    for im in imgs:
+        w0.add_frame(im)
+    assert not w0.open                                                           # closed by itself at the frame limit
+    assert read_avi_frames(str(tmp_path / "t0.avi"))[1] == frames
+    # many frames through few coders: order and count survive the back-pressure
+    w3 = MjpegAviWriter(str(tmp_path / "t3.avi"), 160, 96, fps=30, bitrate_mbps=50.0, workers=2)
+    for k in range(23):
+        w3.add_frame(imgs[k % 4])
+    w3.close()
+    f3 = read_avi_frames(str(tmp_path / "t3.avi"))[1]
+    assert len(f3) == 23 and all(f3[k] == frames[k % 4] for k in range(23))
     # a tight budget lowers the quality, but never below the floor
     big = len(frames[0])
     q = pick_quality(imgs[0], big // 2, q_min=40, q_max=95)
