@@ -13,8 +13,11 @@ method) is provided with the same name, argument meaning and threading contract:
     itself stays in HBM -- reading all of it back after every launch costs 10.9 ms at 4K against a 0.9 ms preview launch
     (moon_renderer.py:1138 calls it once per mouse event).
 
-What differs, by design: there is no Tk window here (no Tk on a headless GPU node) -- `_root`/`_canvas`
-are None and the `_gui_*` handler slots are plain attributes a viewer may call.  One launch adds
+What differs, by design: there is no Tk window here (no Tk on a headless GPU node) -- `_root` / `_canvas` are the
+display-less stand-ins of moonrtx_amd/headless_ui.py (Tk's timer queue `after / after_idle / after_cancel` served by one thread,
+inert window and canvas calls: what moon_renderer.py:398-404, :467-480 and renderer_video.py:213, :361-363 need to run
+unchanged; `headless_ui=False` leaves them None, which the reference reads as "no GUI") and the `_gui_*` handler slots are plain
+attributes a viewer may call.  One launch adds
 `spp_per_launch` samples per pixel (a whole 64-lane wavefront per pixel) instead of one:
 max_accumulation_frames=64 is ONE launch, max_accumulation_frames=1 (the interactive preview,
 moon_renderer.py:457-488) is a 1-spp launch.  The encoder (NVENC H.264 in the reference) writes a Motion-JPEG AVI instead
@@ -95,7 +98,7 @@ class _OptixShim:
 
 class TkOptiX:
     def __init__(self, width=-1, height=-1, on_launch_finished=None, on_rt_completed=None, start_now=False,
-                 device=0, backend=None, progressive=False, **_ignored):
+                 device=0, backend=None, progressive=False, headless_ui=True, **_ignored):
         """`progressive` (this backend's own option, default off): honour `min_accumulation_step` launch by launch as PlotOptiX
         does -- see set_param()."""
         if width <= 0 or height <= 0:
@@ -112,8 +115,10 @@ class TkOptiX:
         self._accum_done_cb = None
         self._optix = _OptixShim(self)
         # viewer plumbing the reference pokes at (moon_renderer.py:998-1201); no Tk here
-        self._root = None
-        self._canvas = None
+        self._root = self._canvas = None
+        if headless_ui:
+            from .headless_ui import HeadlessRoot, HeadlessCanvas
+            self._root, self._canvas = HeadlessRoot(self._width, self._height), HeadlessCanvas(self._width, self._height)
         self._status_action = self._status_action_text = self._status_fps = None
         self._view_orientation = None
         self._any_mouse = self._any_key = self._right_mouse = False
@@ -529,6 +534,8 @@ class TkOptiX:
             self._wake.notify_all()
         if self._thread is not None and self._thread is not threading.current_thread():
             self._thread.join(timeout=10.0)
+        if self._root is not None:
+            self._root.destroy()                 # no callback runs after close()
         with self._padlock:
             if self._encoder is not None:
                 self._encoder.close()

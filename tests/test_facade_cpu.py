@@ -406,3 +406,111 @@ def test_mjpeg_avi_round_trip_and_rate_control(tmp_path):
         w2.add_frame(np.zeros((96, 161, 3), np.uint8))
     w2.close()
     assert read_avi_frames(str(tmp_path / "shape.avi"))[0]["total_frames"] == 0
+
+
+def test_headless_root_is_tks_timer_queue():
+    """after / after_idle / after_cancel as the reference uses them (moon_renderer.py:398-404, :467-480): one thread, due order,
+    cancelled jobs never run, an exception in a callback does not stop the queue."""
+    from moonrtx_amd.headless_ui import HeadlessRoot, HeadlessCanvas
+    root = HeadlessRoot(64, 48)
+    ran, threads = [], set()
+
+    def note(tag):
+        ran.append(tag); threads.add(threading.current_thread().name)
+
+    def boom():
+        raise RuntimeError("callback error (expected in this test)")
+
+    a = root.after(60, note, "late")
+    root.after(20, note, "mid")
+    root.after(0, boom)
+    c = root.after(30, note, "cancelled")
+    root.after_idle(note, "idle")
+    root.after_cancel(c)
+    assert a.startswith("after#") and root.pending() >= 3
+    t0 = time.time()
+    while len(ran) < 3 and time.time() - t0 < 5.0:
+        time.sleep(0.005)
+    assert ran == ["idle", "mid", "late"] and threads == {"moonrt-ui"}
+    root.after_cancel(a); root.after_cancel("after#999")               # done / unknown ids: harmless, as in Tk
+    assert root.wait_idle(2.0) and root.pending() == 0
+    # the inert window calls renderer_status.py / renderer_dialogs.py make
+    root.title("MoonRTX"); root.state("zoomed")
+    assert root.title() == "MoonRTX" and root.state() == "zoomed" and (root.winfo_width(), root.winfo_x(), root.winfo_y()) == (64, 0, 0)
+    seen = []
+    root.bind("<F10>", lambda e: seen.append(("f10", threading.current_thread().name)))
+    root.fire("<F10>"); assert root.wait_idle(2.0) and seen == [("f10", "moonrt-ui")]
+    root.destroy()
+    assert root.after(0, note, "after destroy") is None and root.winfo_exists() == 0
+    # the measuring line of renderer_navigation.py:631-682
+    cv = HeadlessCanvas(64, 48)
+    line = cv.create_line(1, 2, 3, 4, fill="yellow", width=2)
+    cv.coords(line, 1, 2, 30, 40)
+    assert cv.coords(line) == [1.0, 2.0, 30.0, 40.0] and cv.items[line]["options"]["fill"] == "yellow"
+    cv.delete(line); assert cv.items == {} and cv.coords(line) == []
+
+
+def test_preview_restore_and_video_export_run_on_the_headless_queue(tmp_path):
+    """The two flows of the reference that go through rt._root: (1) _begin_interactive_preview / _end_interactive_preview
+    (moon_renderer.py:457-488): single-frame cycles during a burst of edits, converged rendering restored by a timer; (2) the video
+    export's accum-done callback (renderer_video.py:276-363): per frame rt._root.after(0, progress), at the end
+    rt._root.after(delay, finish) where finish stops the encoder on the UI thread."""
+    from moonrtx_amd.video import read_avi_frames
+    rt, be, _ = make()
+    assert rt._root is not None and rt._canvas is not None
+    drive_like_init_renderer(rt, np.zeros((8, 16), np.float32), np.zeros((4, 8, 4), np.uint8))
+    rt.start()
+    # (1) a burst of three edits, each re-arming the restore timer
+    state = {"preview": False, "restore_id": None, "restored_on": None}
+
+    def end_preview():
+        state["restore_id"] = None; state["preview"] = False; state["restored_on"] = threading.current_thread().name
+        rt.set_param(max_accumulation_frames=64); rt.refresh_scene()
+
+    for k in range(3):
+        if not state["preview"]:
+            state["preview"] = True; rt.set_param(max_accumulation_frames=1)
+        if state["restore_id"] is not None:
+            rt._root.after_cancel(state["restore_id"])
+        state["restore_id"] = rt._root.after(40, end_preview)
+        rt.update_light("sun", pos=[10.0 * k, 0.0, 0.0]); rt.refresh_scene()
+        time.sleep(0.01)
+    t0 = time.time()
+    while state["restored_on"] is None and time.time() - t0 < 5.0:
+        time.sleep(0.005)
+    assert state["restored_on"] == "moonrt-ui" and rt.get_param("max_accumulation_frames") == 64
+    spps = [c[2].get("spp_per_launch") for c in be.calls if c[0] == "set_params" and "spp_per_launch" in c[2]]
+    assert 1 in spps and spps[-1] == 64                                # preview launches, then the converged one again
+    # (2) video export, three frames
+    rt.encoder_create(fps=30, bitrate=16)
+    rt.encoder_start(str(tmp_path / "v.avi"), 3)
+    st = {"frame": 0, "progress": [], "finished": threading.Event()}
+
+    def progress(frame, total):
+        st["progress"].append((frame, total, threading.current_thread().name))
+
+    def finish():
+        if rt.encoder_is_open():
+            rt.encoder_stop()
+        st["finished"].set()
+
+    def accum_done(r):                                                  # render thread, padlock held
+        st["frame"] += 1
+        if st["frame"] < 3:
+            r.update_light("sun", pos=[5.0 * st["frame"], 1.0, 0.0]); r.refresh_scene()
+            r._root.after(0, progress, st["frame"], 3)
+        else:
+            r.set_accum_done_cb(None)
+            r._root.after(50, finish)
+
+    rt.set_accum_done_cb(accum_done)
+    rt.refresh_scene()
+    assert st["finished"].wait(20.0)
+    assert st["progress"] == [(1, 3, "moonrt-ui"), (2, 3, "moonrt-ui")]
+    assert not rt.encoder_is_open() and rt.encoded_frames() == 3
+    rt.close()
+    assert rt._root.winfo_exists() == 0
+    assert read_avi_frames(str(tmp_path / "v.avi"))[0]["total_frames"] == 3
+    off = TkOptiX(width=16, height=8, backend=RecordingBackend(16, 8), headless_ui=False)
+    assert off._root is None and off._canvas is None                   # what the reference reads as "no GUI"
+    off.close()
