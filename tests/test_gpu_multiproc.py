@@ -29,3 +29,21 @@ def test_ranks_as_processes_assemble_the_single_rank_frame(native_lib, world, wi
     tail = (p.stdout + p.stderr)[-3000:]
     assert p.returncode == 0, tail
     assert f"MP_GATHER OK world {world}" in p.stdout, tail
+
+
+def test_ranks_on_their_own_gpus_over_rccl(native_lib):
+    """The production transport: one device per rank, torch.distributed backend "nccl" (= RCCL), device-to-device gather.  Needs two
+    GPUs in one box -- the one-GPU boxes this suite normally runs on skip it (counting devices does not initialise the GPU)."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"{n} GPU(s) visible: RCCL needs one device per rank")
+    world = min(n, 4)
+    env = dict(os.environ, MP_WITH_HITS="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env.pop("MOONRT_DIST_BACKEND", None); env.pop("MOONRT_ONE_DEVICE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(HERE, "mp_gather_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    tail = (p.stdout + p.stderr)[-3000:]
+    assert p.returncode == 0, tail
+    assert f"MP_GATHER OK world {world}" in p.stdout, tail
