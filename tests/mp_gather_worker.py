@@ -22,14 +22,14 @@ def main():
     bg = np.random.default_rng(3).integers(0, 255, (64, 128, 4), dtype=np.uint8)
     with_hits = os.environ.get("MP_WITH_HITS", "0") == "1"
     failures = []
-    for name, seg, env in (("S1", (2, 4), None), ("S3", (1, 1), bg)):
+    for idx, (name, seg, env) in enumerate((("S1", (2, 4), None), ("S3", (1, 1), bg))):
         s = named_scene(name, W, H, spp_per_launch=64)
         s.path_seg_min, s.path_seg_max = seg
         rt = MoonRT(W, H, device=local, rank=rank, world=world)
         rt.upload_dem(dem); rt.upload_color(col); rt.upload_background(env); rt.apply_scene(s)
         g = mdist.FrameGather(rt, torch.device("cuda", local), with_hits=with_hits)
         rt.reset()
-        g.render_and_gather(1)
+        g.render_and_gather(1, parts=1 if idx == 0 else 2)     # the second scene in two parts: the overlapped gather (device transports only)
         picks = [(W // 2, H // 2), (W // 2 + 37, H // 2 - 20), (3, 5), (W - 1, H - 1)]
         got_hits = [g.hit_at(x, y) for x, y in picks]          # a collective: every rank calls it
         if rank == 0:
