@@ -635,10 +635,96 @@ __device__ __forceinline__ void segment_tail(const FrameC& f, MarchState& m, flo
     m.ka = ka + SEG_N; m.rowA = rowB; m.colA = colB; m.q2A = q2B;
 }
 
+// Camera rays: the FIRST step of the skip interval [jlo, jhi] that the medium max-mip cannot prove above the surface (jhi + 1 when it
+// proves them all).  A camera ray descends onto the terrain and its march ends at the first step at or below it, so only the front of
+// the interval matters: the steps are tested in march order, four per memory round, and a lane stops at its first inconclusive one.
+// The test itself only has to be CONSERVATIVE, not the spec's arithmetic: the step's texel position from the segment's quadratic at
+// u = j (the spec's u differs by < 3e-4, a thousandth of a texel; a cell's maximum covers two texels more than its own rows and
+// columns on the low side and one more than a bilinear tap needs on the high side, mip_build_kernel), r^2 from the ray's parabola
+// (relative error ~1e-7 against the 1e-5 margin, as in seg_interval).  Result-preserving like every other skip.
+#ifndef MRTX_PMASK_Q
+#define MRTX_PMASK_Q 4        // tests per memory round in render_kernel's marches (cfg3: 2 -> 14.0 ms, 3 -> 13.9, 4 -> 13.75, 6 -> 13.9)
+#endif
+#ifndef MRTX_PATH_MASK_Q
+#define MRTX_PATH_MASK_Q 8    // ... and in path_kernel, which is bound by its dependent memory rounds (4 -> 4.84 ms, 6 -> 4.75, 8 -> 4.64, 16 -> 6.4: spills)
+#endif
+// ... and the mirror image for shadow and continuation rays, which LEAVE the terrain: their first steps are close to the surface,
+// the later ones far above it, so the interval is cut from its END -- the steps are tested backwards from jhi and a lane stops at
+// the first one the medium mip cannot prove above the surface: that is the new jhi (jlo - 1 when every step is proven above).
+template <bool STATS, int Q>
+__device__ __forceinline__ int last_kept_step(const FrameC& f, const MarchState& m, const Seg& sg, uint32_t* cnt) {
+    const float* m2 = CF(f)->mip2;
+    const int pitch = CF(f)->m2_pitch, sh = CF(f)->m2_shift;
+    const uint32_t maxidx = (uint32_t)((CF(f)->m2_h + 2) * pitch - 1);
+    const float two_b = m.rq.b + m.rq.b;
+    int j = sg.jhi;
+    int last = sg.jhi;
+    bool open = (sg.jlo <= sg.jhi) & !sg.exact;
+    if (open) last = sg.jlo - 1;
+    while (open) {
+        float mv[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const float u = (float)max(j - q, sg.jlo);
+            const float rowf = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra), colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
+            const int i = (int)floorf(rowf) >> sh, c = (int)floorf(colf) >> sh;
+            mv[q] = m2[min((uint32_t)((i + 1) * pitch + c + 1), maxidx)];
+        }
+        bool found = false;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int jj = j - q;
+            const float sk = fmaf((float)max(jj, sg.jlo), f.step, sg.sa);
+            const float r2 = fmaf(sk, fmaf(sk, m.rq.a, two_b), m.rq.q0);
+            const float rd = f.Rf * mv[q];
+            const bool kept = !(r2 > (rd * rd) * 1.00001f);
+            if (STATS) cnt[ST_MIP] += (!found && jj >= sg.jlo) ? 1u : 0u;
+            if (!found && jj >= sg.jlo && kept) { last = jj; found = true; }
+        }
+        j -= Q;
+        open = !found && j >= sg.jlo;
+    }
+    return last;
+}
+template <bool STATS, int Q>
+__device__ __forceinline__ int first_kept_step(const FrameC& f, const MarchState& m, const Seg& sg, uint32_t* cnt) {
+    const float* m2 = CF(f)->mip2;
+    const int pitch = CF(f)->m2_pitch, sh = CF(f)->m2_shift;
+    const uint32_t maxidx = (uint32_t)((CF(f)->m2_h + 2) * pitch - 1);
+    const float two_b = m.rq.b + m.rq.b;
+    int j = sg.jlo;
+    int first = sg.jlo;
+    bool open = (sg.jlo <= sg.jhi) & !sg.exact;
+    if (open) first = sg.jhi + 1;
+    while (open) {
+        float mv[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const float u = (float)min(j + q, sg.jhi);
+            const float rowf = fmaf(u, fmaf(u, sg.r2, sg.r1), sg.ra), colf = fmaf(u, fmaf(u, sg.c2, sg.c1), sg.ca);
+            const int i = (int)floorf(rowf) >> sh, c = (int)floorf(colf) >> sh;
+            mv[q] = m2[min((uint32_t)((i + 1) * pitch + c + 1), maxidx)];      // one-cell border; the clamp never bites for a valid segment
+        }
+        bool found = false;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int jj = j + q;
+            const float sk = fmaf((float)min(jj, sg.jhi), f.step, sg.sa);
+            const float r2 = fmaf(sk, fmaf(sk, m.rq.a, two_b), m.rq.q0);
+            const float rd = f.Rf * mv[q];
+            const bool kept = !(r2 > (rd * rd) * 1.00001f);
+            if (STATS) cnt[ST_MIP] += (!found && jj <= sg.jhi) ? 1u : 0u;
+            if (!found && jj <= sg.jhi && kept) { first = jj; found = true; }
+        }
+        j += Q;
+        open = !found && j <= sg.jhi;
+    }
+    return first;
+}
 // ONE 16-step segment of a march (the lanes that call it are still marching): anchors + skip interval, the steps
 // that can be at/below the surface, the termination test at the segment end.  `hit` / `sk_hit` are set by the step
 // that lands at/below the surface, `go` says whether the ray continues with the next segment.
-template <bool WIDE, bool PRIMARY, bool STATS, int BATCH, int CP = 0>
+template <bool WIDE, bool PRIMARY, bool STATS, int BATCH, int CP = 0, int SCAN = PRIMARY ? 1 : 0>
 __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, float smax, Seg& sg, bool& go, bool& hit,
                                               float& sk_hit, uint32_t* cnt) {
     const float oa = m.oa, ob = m.ob, oc = m.oc, da = m.da, db = m.db, dc = m.dc;
@@ -647,6 +733,11 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
     PROF_BEGIN(6);
     seg_setup<STATS>(f, oa, ob, oc, da, db, dc, m.rq, ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
     if (!PRIMARY) sg.jhi = max(min(sg.jhi, m.kend - ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
+    // the medium max-mip cuts the interval once more (first_kept_step / last_kept_step above): camera rays from the front, shadow rays
+    // from the end; MRTX_SEG_MASK bits 2 / 1 switch the two off (A/B)
+    if (SCAN == 1 && (MRTX_SEG_MASK & 4) != 0 && CF(f)->mip2 != nullptr) sg.jlo = first_kept_step<STATS, MRTX_PMASK_Q>(f, m, sg, cnt);
+    if (SCAN == 2 && (MRTX_SEG_MASK & 2) != 0 && CF(f)->mip2 != nullptr) sg.jhi = last_kept_step<STATS, MRTX_PMASK_Q>(f, m, sg, cnt);
+    if (SCAN == 3 && (MRTX_SEG_MASK & 1) != 0 && CF(f)->mip2 != nullptr) sg.jhi = last_kept_step<STATS, MRTX_PMASK_Q>(f, m, sg, cnt);   // A/B: the trial segment
     PROF_END(6);
     PROF_BEGIN(7);
     if (STATS) cnt[ST_HEIGHT] += count_in_steps<PRIMARY>(f, oa, ob, oc, da, db, dc, smax, ka, 1, sg.jlo - 1);
@@ -670,13 +761,13 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
 // PRIMARY: stop when s_k > smax (left the bounding sphere); shadow rays: stop when r^2 > R^2.
 // A lane drops out of the exec mask when it hits or leaves, and the wave leaves the loop when no lane is still
 // marching.  f.kmax is a multiple of SEG_N.
-template <bool WIDE, bool PRIMARY, bool STATS, int BATCH>
+template <bool WIDE, bool PRIMARY, bool STATS, int BATCH, int SCAN = PRIMARY ? 1 : 0>
 __device__ __forceinline__ bool march(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                       float smax, Seg& sg, float& sk_hit, uint32_t* cnt) {
     MarchState m;
     bool hit = false;
     bool go = march_begin<PRIMARY, STATS>(f, oa, ob, oc, da, db, dc, m, cnt);
-    while (go) march_segment<WIDE, PRIMARY, STATS, BATCH>(f, m, smax, sg, go, hit, sk_hit, cnt);
+    while (go) march_segment<WIDE, PRIMARY, STATS, BATCH, 0, SCAN>(f, m, smax, sg, go, hit, sk_hit, cnt);
     return hit;
 }
 
@@ -841,7 +932,7 @@ __device__ __forceinline__ float direct_light(const FrameC& f, const Vertex& v, 
     if (STATS) cnt[ST_SHADOW]++;
     Seg ssg;
     float sk_occ;
-    if (march<WIDE, false, STATS, BATCH>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return 0.0f;
+    if (march<WIDE, false, STATS, BATCH, 2>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt)) return 0.0f;
     return carried;
 }
 
@@ -1356,7 +1447,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         float sk_s = 0.0f, sk_t = 0.0f;
         Seg sgs, sgt;
 #if MRTX_FUSED_TRIAL == 2     // A/B: shared origin coordinates and horizon cell only, the two marches one after the other
-        while (go_s) march_segment<WIDE, false, STATS, BATCH>(f, ms, 0.0f, sgs, go_s, hit_s, sk_s, cnt);
+        while (go_s) march_segment<WIDE, false, STATS, BATCH, 0, 2>(f, ms, 0.0f, sgs, go_s, hit_s, sk_s, cnt);
         if (go_t) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH>(f, mt, 0.0f, sgt, go_t, hit_t, sk_t, cnt);
 #else
         const bool any_s = __ballot(go_s) != 0ull, any_t = __ballot(go_t) != 0ull;
@@ -1365,7 +1456,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
         } else if (any_t) {
             if (go_t) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH>(f, mt, 0.0f, sgt, go_t, hit_t, sk_t, cnt);
         }
-        while (go_s) march_segment<WIDE, false, STATS, BATCH>(f, ms, 0.0f, sgs, go_s, hit_s, sk_s, cnt);
+        while (go_s) march_segment<WIDE, false, STATS, BATCH, 0, 2>(f, ms, 0.0f, sgs, go_s, hit_s, sk_s, cnt);
 #endif
         const float wgt = (have_s && !hit_s) ? carried : 0.0f;
         o.c0 = fmaf(k0, wgt, o.c0);
@@ -1420,9 +1511,9 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 MarchState ms;
                 ms.rowA = org_row; ms.colA = org_col;
                 bool sgo = march_begin_at<false, STATS, false, true>(f, oa, ob, oc, wa, wb, wc, ms, cnt, org_cell);
-                while (sgo) march_segment<WIDE, false, STATS, MRTX_SHADOW_BATCH>(f, ms, 0.0f, ssg, sgo, occluded, sk_occ, cnt);
+                while (sgo) march_segment<WIDE, false, STATS, MRTX_SHADOW_BATCH, 0, 2>(f, ms, 0.0f, ssg, sgo, occluded, sk_occ, cnt);
 #else
-                occluded = march<WIDE, false, STATS, BATCH>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt);
+                occluded = march<WIDE, false, STATS, BATCH, 2>(f, oa, ob, oc, wa, wb, wc, 0.0f, ssg, sk_occ, cnt);
 #endif
             }
             park_fence();
@@ -1497,7 +1588,7 @@ __device__ __forceinline__ void trace_sample(const FrameC& f, int lt, int x, int
                 bool thit = false;
                 Seg tsg;
                 float tsk = 0.0f;
-                if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH, MRTX_TRIAL_CP>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
+                if (tgo) march_segment<WIDE, false, STATS, MRTX_TRIAL_BATCH, MRTX_TRIAL_CP, 3>(f, tm, 0.0f, tsg, tgo, thit, tsk, tcnt);
                 if (PARK) {
                     park_fence();
                     const v4f p0 = park_get(park, 0), p1 = park_get(park, 1);
@@ -2104,6 +2195,7 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                     if (STATS) cnt[ST_HEIGHT] += count_in_steps<false>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, 0.0f, m.ka, 1, sg.jlo - 1);
                     m.rowA = rowB; m.colA = colB; m.q2A = q2B;   // the next segment starts where this one ends
                     sg.jhi = max(min(sg.jhi, m.kend - m.ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
+                    if ((MRTX_SEG_MASK & 8) != 0 && CF(f)->mip2 != nullptr) sg.jhi = last_kept_step<STATS, MRTX_PATH_MASK_Q>(f, m, sg, cnt);
                     j = sg.jlo;
 #if MRTX_PATH_MIP2
                     todo = j <= sg.jhi ? (((2u << (sg.jhi - 1)) - 1u) & ~((1u << (j - 1)) - 1u)) : 0u;      // steps j .. jhi

@@ -206,6 +206,71 @@ def test_production_kernels_equal_the_counting_kernels_at_full_size(inputs):
         assert_bit_equal(frames[1][1], frames[0][1], f"production vs counting hits, {spp} spp, path_seg {seg}")
 
 
+def _skip_vs_full(rt_factory, what):
+    """One frame with every result-preserving skip (max-mip interval, medium-mip scans, horizon cut) and one with none of them
+    (MRTX_F_NO_SKIP): radiance, hits and the spec counters must be the same bits over the WHOLE frame."""
+    from common import STAT_KEYS
+    out = {}
+    for tag, flags in (("skip", _lib.F_COUNT_STATS), ("full", _lib.F_COUNT_STATS | _lib.F_NO_SKIP)):
+        rt = rt_factory()
+        rt.set_params(flags=flags)
+        st = rt.render(1)
+        out[tag] = (rt.read_linear(), rt.read_hits(), st)
+        rt.close()
+    assert_bit_equal(out["skip"][0], out["full"][0], f"{what}: skip vs full radiance")
+    assert_bit_equal(out["skip"][1], out["full"][1], f"{what}: skip vs full hits")
+    a, b = out["skip"][2], out["full"][2]
+    assert {k: a[k] for k in STAT_KEYS} == {k: b[k] for k in STAT_KEYS}, (what, a, b)
+    assert b["mip_fetches"] == 0 and 0 < a["dem_fetches"] < 0.6 * b["dem_fetches"]
+    return a
+
+
+def test_skips_are_result_preserving_over_the_whole_full_size_frame(inputs):
+    """Every skip is a PROOF that a step lies above the surface: at cfg3's texel density -- 3.7 texels per
+    march step times tan(incidence), where a segment's steps cross several medium-mip cells and grazing rays at the limb run through
+    hundreds of them -- the whole 4K frame (8.3 M pixels x 4 samples, paths of 2-4 segments) must not differ in one bit from the
+    frame marched without any of them.  Scenes S1 (phase 77 deg) and S3 (135 deg: grazing light, long shadows)."""
+    for name in ("S1", "S3"):
+        def factory():
+            rt = make(inputs, 4)
+            s = named_scene(name, W, H, spp_per_launch=4)
+            s.path_seg_min, s.path_seg_max = 2, 4
+            rt.apply_scene(s)
+            return rt
+        _skip_vs_full(factory, name)
+
+
+def test_skips_are_result_preserving_on_a_spiked_dem(inputs, host_inputs):
+    """... and on terrain built to defeat a careless bound: single-texel spikes 7 km tall and pits 7 km deep, three-texel mesas and
+    cliffs along lines that are not aligned with any mip cell, so that neighbouring medium-mip cells differ by a dozen march steps
+    and a test that looks at the wrong cell, or at a position a texel off, misses a hit."""
+    dem = host_inputs[0].copy()
+    dem[11::97, 7::89] += 0.004            # spikes (D is clipped to its maximum 1.0 below: the bounding sphere is R)
+    dem[40::101, 33::83] -= 0.004          # pits
+    for dr in range(3):
+        for dc in range(3):
+            dem[60 + dr::211, 15 + dc::197] += 0.003      # mesas
+    dem[:, 5::1009] += 0.002               # meridional walls one texel wide
+    dem[13::1013, :] += 0.002              # zonal walls
+    np.clip(dem, 0.98, 1.0, out=dem)
+    col_b = inputs[1]
+    for name, vfov in (("S1", None), ("S1", 0.7)):
+        def factory():
+            rt = MoonRT(W, H)
+            rt.upload_dem(dem)
+            rt.bind_color(col_b, COL_H, COL_W)
+            if vfov:
+                from moonrtx_amd.scene import zoomed_on_terminator
+                s = zoomed_on_terminator(name, W, H, vfov_deg=vfov, spp_per_launch=2)
+            else:
+                s = named_scene(name, W, H, spp_per_launch=2)
+            s.path_seg_min, s.path_seg_max = 2, 4
+            rt.apply_scene(s)
+            return rt
+        st = _skip_vs_full(factory, f"spiked DEM, {name}, vfov {vfov}")
+        assert st["primary_hits"] > 1_000_000
+
+
 def test_quadratic_texel_coordinates_error_budget_in_radiance(inputs):
     """The spec evaluates texel coordinates exactly at three anchors per 16-step segment and by a quadratic in between
     (DESIGN.md section 3.3).  Against exact evaluation at EVERY step (orc.set_exact) at cfg3's texel density, 64 spp:

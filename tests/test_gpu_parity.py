@@ -460,7 +460,10 @@ def test_hitless_exchange_config_and_stage_counters(native_lib, dem_small):
         assert 0 < st_1["camera_" + k] <= st_1[k] if st_1[k] else st_1["camera_" + k] == 0, (k, st_1)
     assert st_1["camera_dem_fetches"] < st_1["dem_fetches"] and st_1["camera_height_samples"] < st_1["height_samples"]
     _, _, st_w, _ = render_hip(s, dem_small, tile=(16, 16), flags=_lib.F_COUNT_STATS | _lib.F_INWAVE_PATHS)
-    assert all(st_w["camera_" + k] == st_w[k] == st_1[k] for k in ("height_samples", "dem_fetches", "colour_fetches"))
+    assert all(st_w["camera_" + k] == st_w[k] == st_1[k] for k in ("height_samples", "colour_fetches"))
+    # the evaluations actually PERFORMED are an implementation count: path_kernel cuts every march's skip intervals with the medium
+    # mip, the in-wave kernel only those of its camera and shadow rays (round 4), so the two modes agree in the spec counters only
+    assert st_w["camera_dem_fetches"] == st_w["dem_fetches"] > 0
     d = MoonRT(64, 48); cfg1 = d.config(); d.close()
     d = MoonRT(64, 48, rank=1, world=4); cfg4 = d.config(); d.close()
     assert (cfg1["tile_w"], cfg1["tile_h"], cfg1["world"]) == (16, 16, 1) and (cfg4["tile_w"], cfg4["tile_h"], cfg4["rank"], cfg4["world"]) == (32, 32, 1, 4)
