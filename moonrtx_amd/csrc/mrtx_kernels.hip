@@ -316,7 +316,13 @@ __device__ __forceinline__ void exact_rowcol(const FrameC& f, float pa, float pb
 // termination test is monotone, so it is enough to apply it at evaluated steps and at the segment end.
 // seg_setup in two phases, so that a caller can put OTHER work between the max-mip fetch and its use (fused_first_segment):
 // seg_anchors = the anchors, the quadratic and WHERE the max-mip is to be read; seg_interval = the skip interval from the cells.
-struct MipTap { uint32_t off; bool usable, two_r, two_c; };
+#ifndef MRTX_WIDE_TAP
+#define MRTX_WIDE_TAP 1       // a footprint of up to MRTX_TAP_COLS cells along the columns still gets its skip interval (see seg_anchors)
+#endif
+#ifndef MRTX_TAP_COLS
+#define MRTX_TAP_COLS 4
+#endif
+struct MipTap { uint32_t off; bool usable, two_r, two_c; int ncol; };
 __device__ __forceinline__ void seg_anchors(const FrameC& f, float oa, float ob, float oc, float da, float db, float dc,
                                             int ka, float rowA, float colA, float q2A, Seg& sg,
                                             float& rowB, float& colB, float& q2B, MipTap& tap) {
@@ -335,15 +341,18 @@ __device__ __forceinline__ void seg_anchors(const FrameC& f, float oa, float ob,
     sg.c1 = fmaf(-16.0f, sg.c2, (colB - colA) * 0.0625f);
 
     sg.jlo = 1; sg.jhi = SEG_N;
-    tap.usable = false; tap.two_r = tap.two_c = false; tap.off = 0u;
+    tap.usable = false; tap.two_r = tap.two_c = false; tap.off = 0u; tap.ncol = 1;
     if (f.mip != nullptr) {
         const int i0 = ((int)floorf(fminf(rowA, fminf(rM, rowB))) - 1) >> f.mip_shift;
         const int i1 = ((int)floorf(fmaxf(rowA, fmaxf(rM, rowB))) + 2) >> f.mip_shift;
         const int j0 = ((int)floorf(fminf(colA, fminf(cM, colB))) - 1) >> f.mip_shift;
         const int j1 = ((int)floorf(fmaxf(colA, fmaxf(cM, colB))) + 2) >> f.mip_shift;
-        tap.usable = !sg.exact & (i1 - i0 <= 1) & (j1 - j0 <= 1) & (i0 >= -1) & (i1 <= f.mip_h) & (j0 >= -1) &
+        // Columns shrink with cos(latitude): a ray that travels east-west at 30 degrees of latitude already covers more columns in
+        // 16 steps than a cell is wide, and round 4 found 23 % of all camera and shadow segments of the cfg3 frame WITHOUT a skip
+        // interval for that reason alone.  Up to four cells along the columns are therefore allowed (a second 16-byte load).
+        tap.usable = !sg.exact & (i1 - i0 <= 1) & (j1 - j0 <= (MRTX_WIDE_TAP ? MRTX_TAP_COLS - 1 : 1)) & (i0 >= -1) & (i1 <= f.mip_h) & (j0 >= -1) &
                      (j1 <= f.mip_w);
-        tap.two_r = i1 > i0; tap.two_c = j1 > j0;
+        tap.two_r = i1 > i0; tap.two_c = j1 > j0; tap.ncol = j1 - j0 + 1;
         // the mip is stored in row pairs as well (element (i, j) = (m[i][j], m[i+1][j])): one 16-byte load brings the
         // 2x2 cells at (i0, j0); the ones the footprint does not reach are ignored, so the bound is the old one
         tap.off = tap.usable ? ((uint32_t)((i0 + 1) * f.mip_pitch + j0 + 1) << 3) : 0u;
@@ -354,8 +363,8 @@ __device__ __forceinline__ Quad mip_fetch(const FrameC& f, const MipTap& tap) {
 }
 template <bool STATS>
 __device__ __forceinline__ void seg_interval(const FrameC& f, const RayQ& rq, Seg& sg, const MipTap& tap, const Quad& q,
-                                             uint32_t* cnt) {
-    const float dmax = fmaxf(fmaxf(q.a, tap.two_r ? q.b : q.a), fmaxf(tap.two_c ? q.c : q.a, (tap.two_r & tap.two_c) ? q.d : q.a));
+                                             uint32_t* cnt, float dmax_more = 0.0f) {
+    const float dmax = fmaxf(fmaxf(fmaxf(q.a, tap.two_r ? q.b : q.a), fmaxf(tap.two_c ? q.c : q.a, (tap.two_r & tap.two_c) ? q.d : q.a)), dmax_more);
     if (STATS) cnt[ST_MIP] += 4;
     const float rd = f.Rf * dmax;
     const float T = (rd * rd) * 1.00001f;
@@ -378,7 +387,19 @@ __device__ __forceinline__ void seg_setup(const FrameC& f, float oa, float ob, f
     seg_anchors(f, oa, ob, oc, da, db, dc, ka, rowA, colA, q2A, sg, rowB, colB, q2B, tap);
     if (tap.usable) {
         const Quad q = mip_fetch(f, tap);
-        seg_interval<STATS>(f, rq, sg, tap, q, cnt);
+        float more = 0.0f;       // D > 0 everywhere: zero is neutral for the maximum
+        if (MRTX_WIDE_TAP) {
+#pragma unroll
+            for (int c = 2; c < MRTX_TAP_COLS; c += 2) {      // columns j0 + c (and j0 + c + 1): the next two cells of the same row pair
+                if (tap.ncol > c) {
+                    const Quad q2 = *reinterpret_cast<const Quad*>(reinterpret_cast<const char*>(f.mip) + tap.off + 8u * (uint32_t)c);
+                    more = fmaxf(more, fmaxf(q2.a, tap.two_r ? q2.b : q2.a));
+                    if (tap.ncol > c + 1) more = fmaxf(more, fmaxf(q2.c, tap.two_r ? q2.d : q2.c));
+                    if (STATS) cnt[ST_MIP] += 4;
+                }
+            }
+        }
+        seg_interval<STATS>(f, rq, sg, tap, q, cnt, more);
     }
 }
 
@@ -732,6 +753,10 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
     float rowB, colB, q2B;
     PROF_BEGIN(6);
     seg_setup<STATS>(f, oa, ob, oc, da, db, dc, m.rq, ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
+#ifdef MRTX_PROF_FULLIV   // measurement only: how many lanes get NO skip interval from the max-mip (footprint over more than 2 x 2 cells, or a true full interval)
+    { const bool full = (sg.jlo == 1) & (sg.jhi == SEG_N) & !sg.exact;
+      cnt[13] += (uint32_t)__popcll(__ballot(full)); cnt[14] += (uint32_t)__popcll(__ballot(sg.exact)); }
+#endif
     if (!PRIMARY) sg.jhi = max(min(sg.jhi, m.kend - ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
     // the medium max-mip cuts the interval once more (first_kept_step / last_kept_step above): camera rays from the front, shadow rays
     // from the end; MRTX_SEG_MASK bits 2 / 1 switch the two off (A/B)
@@ -747,11 +772,14 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
         step_loop<WIDE, PRIMARY, STATS, false, BATCH, CP>(f, oa, ob, oc, da, db, dc, smax, sg, ka, go, hit, sk_hit, cnt);
     PROF_END(7);
 #ifdef MRTX_PROF
-#if !defined(MRTX_PROF_SPREAD) && !defined(MRTX_PROF_TRIAL)
+#if !defined(MRTX_PROF_SPREAD) && !defined(MRTX_PROF_TRIAL) && !defined(MRTX_PROF_FULLIV)
     cnt[8] += 1;                                     // wave-level segments
     cnt[9] += (uint32_t)__popcll(__ballot(true));    // lanes alive in them
     cnt[PRIMARY ? 13 : 14] += (__ballot(sg.jlo <= sg.jhi) == 0ull) ? 1u : 0u;   // wave-level segments nobody steps in
     cnt[15] += PRIMARY ? 1u : 0u;
+#endif
+#ifdef MRTX_PROF_FULLIV
+    cnt[8] += 1; cnt[9] += (uint32_t)__popcll(__ballot(true));
 #endif
 #endif
     segment_tail<PRIMARY, STATS>(f, m, smax, sg, go, rowB, colB, q2B, cnt);
@@ -1089,6 +1117,9 @@ __device__ __forceinline__ float nearest_capsule(const FrameC& f, int lt, float 
 #define MRTX_FUSED_TRIAL 0     // 1 = fused first segment, 2 = shared origin only, 0 = one march after the other (ships)
 #endif
 #if MRTX_FUSED_TRIAL == 1
+#if MRTX_WIDE_TAP
+#error "fused_first_segment reads one max-mip element pair per ray: build it with -DMRTX_WIDE_TAP=0"
+#endif
 template <bool WIDE, bool STATS>
 __device__ __forceinline__ void fused_first_segment(const FrameC& f, MarchState& ms, MarchState& mt, Seg& sgs, Seg& sgt,
                                                     bool& go_s, bool& go_t, bool& hit_s, bool& hit_t, float& sk_s, float& sk_t,
