@@ -669,7 +669,7 @@ static int ensure_mip(mrtx_ctx* c) {
     if (e == hipSuccess) e = mrtx_launch_hmip(plain, c->mip_h, c->mip_w, shift, c->hmip, c->hm_h, c->hm_w, c->hm_shift, c->dem_h, c->dem_w, c->stream);
     // medium max-mip: the same cell maxima (dilated by the two-texel tap border) at a quarter of the cell size -- 16 texels at cfg3,
     // 17 MB: what path_kernel tests the steps of a segment against before it fetches the DEM for them
-    c->m2_shift = shift - 2 < 2 ? 2 : shift - 2;
+    c->m2_shift = shift - MRTX_M2_DELTA < 2 ? 2 : shift - MRTX_M2_DELTA;
     if ((MRTX_PATH_MIP2 | MRTX_SEG_MASK) != 0) {
         const int c2 = 1 << c->m2_shift;
         c->m2_h = (c->dem_h + c2 - 1) / c2; c->m2_w = (c->dem_w + c2 - 1) / c2;

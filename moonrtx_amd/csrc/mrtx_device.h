@@ -53,6 +53,9 @@ static inline int mrtx_tile_shift(int world) {
 // (first_kept_step / last_kept_step in mrtx_kernels.hip; round 4): bit 2 (4) camera rays, from the front: render 15.4 -> 13.9 ms at cfg3;
 // bit 1 (2) shadow rays in render_kernel, from the end: -> 13.8; bit 3 (8) path_kernel's marches, from the end: path stage 5.0 -> 4.65;
 // bit 0 (1) the trial segment, from the end: +0.17 ms, off.  The host builds the medium mip when either switch is set.
+#ifndef MRTX_M2_DELTA
+#define MRTX_M2_DELTA 2      // medium-mip cell = max-mip cell >> MRTX_M2_DELTA (never below 4 texels)
+#endif
 #ifndef MRTX_SEG_MASK
 #define MRTX_SEG_MASK 14
 #endif

@@ -578,6 +578,20 @@ __device__ __forceinline__ int horizon_kend(const FrameC& f, const MarchState& m
     }
     return kend;
 }
+// horizon_kend() asked again from the start of segment m.ka (texel coordinates m.rowA / m.colA, rho^2 = m.q2A): the parabola's
+// coefficients moved to that point.  Steps are counted from there; f.kmax = nothing known.
+#ifndef MRTX_HORIZON_RETRY
+#define MRTX_HORIZON_RETRY 2     // bit 0: render_kernel's shadow marches (measured: +0.55 ms, the test runs for the whole wave), bit 1: path_kernel (-0.13 ms)
+#endif
+__device__ __forceinline__ int horizon_retry(const FrameC& f, const MarchState& m) {
+    const float s = (float)m.ka * f.step;
+    MarchState t;
+    t.rq.a = m.rq.a;
+    t.rq.b = fmaf(m.rq.a, s, m.rq.b);
+    t.rq.q0 = fmaf(s, fmaf(s, m.rq.a, m.rq.b + m.rq.b), m.rq.q0);
+    t.q2A = m.q2A; t.rowA = m.rowA; t.colA = m.colA;
+    return horizon_kend(f, t);
+}
 // STATS builds: the steps the spec evaluates after a march was cut at kend (every step while the ray is inside)
 __device__ __forceinline__ uint32_t steps_after(const FrameC& f, const MarchState& m, int k_from) {
     uint32_t n = 0;
@@ -751,6 +765,18 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
     const float oa = m.oa, ob = m.ob, oc = m.oc, da = m.da, db = m.db, dc = m.dc;
     const int ka = m.ka;
     float rowB, colB, q2B;
+    if (!PRIMARY && (MRTX_HORIZON_RETRY & 1) != 0 && ka > 0 && m.kend >= f.kmax) {
+        // The horizon bound was out of reach at the ray's origin (its ground track to the sphere exit is longer than the horizon
+        // cell's dilation: low rays, and any east-west ray at high latitude, where columns shrink).  The ray has climbed since:
+        // asked again from HERE, the remaining track is shorter and the bound may apply.
+        const int ke = horizon_retry(f, m);
+        if (ke < 1) {                        // above everything in reach already: the march ends before this segment
+            if (STATS) cnt[ST_HEIGHT] += steps_after(f, m, ka + 1);
+            go = false;
+            return;
+        }
+        m.kend = min(f.kmax, ka + ke);       // ke == kmax: still unknown
+    }
     PROF_BEGIN(6);
     seg_setup<STATS>(f, oa, ob, oc, da, db, dc, m.rq, ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
 #ifdef MRTX_PROF_FULLIV   // measurement only: how many lanes get NO skip interval from the max-mip (footprint over more than 2 x 2 cells, or a true full interval)
@@ -2212,6 +2238,10 @@ __global__ void __launch_bounds__(64, STATS ? 2 : MRTX_PATH_WAVES) path_kernel(c
                 const uint32_t mip0 = STATS ? cnt[ST_MIP] : 0u;
                 const bool open_kend = m.kend < 0;          // first segment of a march begun in this kernel: the horizon
                 if (open_kend) m.kend = horizon_kend(f, m); // bound is looked up beside the max-mip (one memory round)
+                else if ((MRTX_HORIZON_RETRY & 2) != 0 && known_hit >= 0 && m.ka > 0 && m.kend >= f.kmax) {
+                    const int ke = horizon_retry(f, m);     // out of reach at the origin: asked again from here (see march_segment)
+                    m.kend = ke < f.kmax ? m.ka + max(ke, 0) : f.kmax;
+                }
                 seg_setup<STATS>(f, m.oa, m.ob, m.oc, m.da, m.db, m.dc, m.rq, m.ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
                 if (open_kend && m.kend < 1) {
                     // already above everything in reach: no step can hit, the march ends before its first segment
