@@ -1026,7 +1026,10 @@ int mrtx_render_part(mrtx_ctx* c, int32_t n_blocks, int32_t part, int32_t n_part
         PathQ& pq = pqs[(size_t)s];
         const size_t set = overlap ? (size_t)(s & 1) : 0;     // ping-pong: sub-part s hands over through buffer set s % 2
         pq.ray0 = reinterpret_cast<float4*>(reinterpret_cast<char*>(c->path_rec) + set * n * MRTX_PATH_REC_BYTES); pq.ray1 = pq.ray0 + n; pq.ray2 = pq.ray1 + n;
-#if MRTX_C_AOS
+#if MRTX_C_AOS == 2
+        pq.c4 = pq.ray2 + n; pq.c0 = pq.c1 = pq.c2 = nullptr;
+        pq.lane_of = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(pq.c4) + 3 * n);     // 12 bytes per sample
+#elif MRTX_C_AOS
         pq.c4 = pq.ray2 + n; pq.c0 = pq.c1 = pq.c2 = nullptr;
         pq.lane_of = reinterpret_cast<uint32_t*>(pq.c4 + n);
 #else

@@ -145,7 +145,7 @@ struct FrameC {
 struct PathQ {
     float4* ray0; float4* ray1; float4* ray2;
     float* c0; float* c1; float* c2;
-    float4* c4;                 // MRTX_C_AOS: the three of them as one float4 per sample (one 16-byte access instead of three sectors)
+    float4* c4;                 // MRTX_C_AOS 1: the three of them as one float4 per sample (one 16-byte access instead of three sectors); 2: packed, 12 bytes per sample
     uint32_t* lane_of;          // per ray record: lane + the state of its march after the trial segment (see above)
     uint8_t* npaths;            // per chunk: ray records it holds (0 for a chunk that was not deferred): zero before the launch
     uint32_t* meta;
@@ -163,9 +163,11 @@ struct PathQ {
 };
 // The running radiance of a sample as ONE float4 per sample (round 3): a path that adds light reads and writes one 64-byte sector
 // instead of three in three arrays -- path stage 5.41 -> 5.19 ms at cfg3, render and resolve unchanged (0 = the three float arrays)
+// 2 (round 4): the three floats PACKED, 12 bytes per sample -- resolve_paths_kernel streams a quarter less, the render kernel writes a
+// quarter less, a path's read-modify-write still touches one sector five times in eight: path stage 4.35 -> 4.28 ms, frame -0.12 ms
 #ifndef MRTX_C_AOS
-#define MRTX_C_AOS 1
+#define MRTX_C_AOS 2
 #endif
-#define MRTX_PATH_REC_BYTES (MRTX_C_AOS ? 68 : 64)  // per record: 3 x float4 + 3 x float (or one float4) + 1 word
+#define MRTX_PATH_REC_BYTES (MRTX_C_AOS == 1 ? 68 : 64)  // per record: 3 x float4 + 3 x float (or one float4) + 1 word
 #define MRTX_REC_RESUME 64u
 #define MRTX_REC_HIT 128u

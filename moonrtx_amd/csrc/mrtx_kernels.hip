@@ -210,15 +210,21 @@ __device__ __forceinline__ float4 nt_load4(const float4* p) {
 }
 
 // a sample's running radiance in the hand-over buffers (PathQ::c0/c1/c2, or one float4 per sample with MRTX_C_AOS)
+typedef float v3f __attribute__((ext_vector_type(3)));
+struct __attribute__((packed, aligned(4))) Tri { float x, y, z; };
 __device__ __forceinline__ void c_load(const PathQ& pq, uint32_t e, float& c0, float& c1, float& c2) {
-#if MRTX_C_AOS
+#if MRTX_C_AOS == 2
+    const Tri v = reinterpret_cast<const Tri*>(pq.c4)[e]; c0 = v.x; c1 = v.y; c2 = v.z;
+#elif MRTX_C_AOS
     const float4 v = pq.c4[e]; c0 = v.x; c1 = v.y; c2 = v.z;
 #else
     c0 = pq.c0[e]; c1 = pq.c1[e]; c2 = pq.c2[e];
 #endif
 }
 __device__ __forceinline__ void c_store(const PathQ& pq, uint32_t e, float c0, float c1, float c2) {
-#if MRTX_C_AOS
+#if MRTX_C_AOS == 2
+    { Tri v; v.x = c0; v.y = c1; v.z = c2; reinterpret_cast<Tri*>(pq.c4)[e] = v; }
+#elif MRTX_C_AOS
     pq.c4[e] = make_float4(c0, c1, c2, 0.0f);
 #else
     pq.c0[e] = c0; pq.c1[e] = c1; pq.c2[e] = c2;
@@ -1896,7 +1902,10 @@ render_kernel(const FrameC f, const PathQ pq) {
                     nt_store4(pq.ray2 + es, o.t2, o.row, o.col, __uint_as_float(o.ks));
                     pq.lane_of[es] = (uint32_t)lane | o.aux;
                 }
-#if MRTX_C_AOS
+#if MRTX_C_AOS == 2
+                { float* const cp = reinterpret_cast<float*>(pq.c4) + 3u * (size_t)e;
+                  __builtin_nontemporal_store(o.c0, cp); __builtin_nontemporal_store(o.c1, cp + 1); __builtin_nontemporal_store(o.c2, cp + 2); }
+#elif MRTX_C_AOS
                 nt_store4(pq.c4 + e, o.c0, o.c1, o.c2, 0.0f);
 #else
                 __builtin_nontemporal_store(o.c0, pq.c0 + e);
@@ -2665,7 +2674,10 @@ __global__ void __launch_bounds__(256) resolve_paths_kernel(const FrameC f, cons
             acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (mt[u] & 0x80000000u) {                       // wave-uniform
                 const uint32_t e = (base + u) * 64u + lane;
-#if MRTX_C_AOS
+#if MRTX_C_AOS == 2
+                { const float* const cp = reinterpret_cast<const float*>(pq.c4) + 3u * (size_t)e;
+                  a0[u] = __builtin_nontemporal_load(cp); a1[u] = __builtin_nontemporal_load(cp + 1); a2[u] = __builtin_nontemporal_load(cp + 2); }
+#elif MRTX_C_AOS
                 { const float4 v = nt_load4(pq.c4 + e); a0[u] = v.x; a1[u] = v.y; a2[u] = v.z; }
 #else
                 a0[u] = __builtin_nontemporal_load(pq.c0 + e);
