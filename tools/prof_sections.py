@@ -17,6 +17,9 @@ dem_buf, _ = dem_from_ldem(src, dem_h, dem_w, 1, device=0)
 src.free()
 col = synth_color(col_shape[0], col_shape[1], device=0)
 scene = named_scene(sc, W, H, spp_per_launch=64)
+if os.environ.get("ZOOM"):      # the zoomed terminator view (bench.py's also_zoomed): ZOOM=0.7
+    from moonrtx_amd.scene import zoomed_on_terminator
+    scene = zoomed_on_terminator(sc, W, H, vfov_deg=float(os.environ["ZOOM"]), spp_per_launch=64)
 if os.environ.get("PATH_SEG"):
     scene.path_seg_min, scene.path_seg_max = [int(t) for t in os.environ["PATH_SEG"].split(",")]
 rt = MoonRT(W, H, device=0)
