@@ -84,7 +84,27 @@ def random_scene(rng):
 
 
 
-def cases(seed, exotic=None):
+def dense_dem(rng, h):
+    """A DEM dense enough for a march step to cross SEVERAL texels (and medium-mip cells every few steps) -- what the small fuzz DEMs
+    never do: blocky terraces with white noise on top, single-texel spikes and pits, one-texel walls, none aligned with a mip cell."""
+    w = 2 * h
+    relief = float(rng.choice([0.004, 0.012, 0.03]))
+    blk = int(rng.choice([5, 11, 23, 47]))
+    coarse = np.floor(rng.random((h // blk + 2, w // blk + 2)) * 4) / 4.0
+    d = np.kron(coarse, np.ones((blk, blk), np.float32))[:h, :w] * 0.7 + rng.random((h, w), dtype=np.float32) * 0.1
+    n = int(rng.integers(200, 4000))
+    d[rng.integers(0, h, n), rng.integers(0, w, n)] = 1.0            # spikes
+    d[rng.integers(0, h, n), rng.integers(0, w, n)] = 0.0            # pits
+    for _ in range(int(rng.integers(0, 6))):
+        d[:, rng.integers(0, w)] += 0.2                              # meridional walls
+        d[rng.integers(0, h), :] += 0.2                              # zonal walls
+    np.clip(d, 0.0, 1.0, out=d)
+    d = (1.0 - relief + relief * d).astype(np.float32)
+    d.flat[rng.integers(0, d.size)] = 1.0
+    return d
+
+
+def cases(seed, exotic=None, dense=None):
     """Endless generator of (description, dem, colour, background, scene, flags, tile, blocks, extra); `extra` =
     dict(capsules, world, parts) drawn from a second stream, so case k of a seed keeps its scene as options are added."""
     rng = np.random.default_rng(seed)
@@ -93,6 +113,9 @@ def cases(seed, exotic=None):
     if exotic is None:
         exotic = bool(os.environ.get("FUZZ_EXOTIC"))   # campaign option: the rare combinations (camera inside the shell of overlay
     p_bg, p_caps, p_inside = (0.7, 0.7, 0.5) if exotic else (0.3, 0.25, 0.12)   # tubes, environment map, paths) in most cases
+    if dense is None:
+        dense = bool(os.environ.get("FUZZ_DENSE"))     # campaign option (round 4): most cases on a DENSE DEM with long march steps
+    p_dense = 0.7 if dense else 0.0                    # off by default: case k of a seed stays what it was
     while True:
         dem = random_dem(rng)
         col = (rng.integers(0, 256, (int(rng.integers(2, 40)), int(rng.integers(2, 70)), 4), dtype=np.uint8)
@@ -133,6 +156,10 @@ def cases(seed, exotic=None):
         extra["inwave"] = bool(rng2.random() < 0.35)   # D6 inside the render wave instead of behind the path queue
         if rng2.random() < 0.3:                     # the "Gamma" post-process away from its defaults (round 3: the 8-bit image is compared too)
             s.gamma = float(rng2.choice([0.5, 1.0, 1.8, 3.3, 5.0])); s.exposure = float(rng2.uniform(0.3, 3.0))
+        if rng2.random() < p_dense:                 # drawn last from the second stream: earlier draws keep their values
+            dem = dense_dem(rng2, int(rng2.choice([720, 1440, 2880])))
+            s.marching_step = float(rng2.choice([1.3e-2, 3e-2, 5e-2])) * (s.radius / 10.0)      # 1 ... 4.6 texels per step at h = 2880
+            s.marching_step_eps = float(s.marching_step * rng2.choice([0.06, 0.2, 0.5]))
         desc = (f"seed {seed} case {case}: dem {dem.shape} frame {s.width}x{s.height} S={s.spp_per_launch} "
                 f"seg=({s.path_seg_min},{s.path_seg_max}) fov {s.vfov_deg:.2f} step {s.marching_step:.2g} flags {flags} tile {tile} "
                 f"blocks {blocks} col {None if col is None else col.shape[:2]} bg {None if bg is None else bg.shape[:2]} "

@@ -33,6 +33,17 @@ def test_exotic_cases_match_the_oracle(native_lib):
     assert total > 100000
 
 
+def test_dense_dem_cases_match_the_oracle(native_lib):
+    """Round 4's medium-mip scans decide per STEP which cell bounds it; the ordinary fuzz DEMs (<= 360 rows) keep a ray inside one
+    cell for dozens of steps.  FUZZ_DENSE cases put 720 ... 2 880-row terrains of terraces, spikes, pits and one-texel walls under
+    march steps of 1 ... 4.6 texels, with the generator's random cameras (limb-grazing, close-ups, inside the shell): the first 16
+    cases of dense seed 21 in the driver-run suite, campaigns in profiles/r04_fuzz_campaign.log."""
+    total = 0
+    for c in itertools.islice(fuzz_cases.cases(21, dense=True), 16):
+        total += fuzz_cases.check_case(c)["primary_rays"]
+    assert total > 50000
+
+
 def test_heavily_spilled_instantiation_matches_the_oracle():
     """Round 1 reported one miscomputed sample from render_kernel<64, STATS, !WIDE, in-wave paths, OVERLAY> under a 72-VGPR cap
     (~270 spilled VGPRs); the failing case was not kept and the march state has been restructured since (every field
