@@ -682,7 +682,8 @@ __device__ __forceinline__ void segment_tail(const FrameC& f, MarchState& m, flo
 // The test itself only has to be CONSERVATIVE, not the spec's arithmetic: the step's texel position from the segment's quadratic at
 // u = j (the spec's u differs by < 3e-4, a thousandth of a texel; a cell's maximum covers two texels more than its own rows and
 // columns on the low side and one more than a bilinear tap needs on the high side, mip_build_kernel), r^2 from the ray's parabola
-// (relative error ~1e-7 against the 1e-5 margin, as in seg_interval).  Result-preserving like every other skip.
+// (its terms are ~R^2 each and s reaches 2R: good to ~1e-6 relative, a tenth of the comparison's 1e-5 margin -- the margin seg_interval
+// has relied on since round 1; the evaluation's own r^2 is as close to the true value).  Result-preserving like every other skip.
 #ifndef MRTX_PMASK_Q
 #define MRTX_PMASK_Q 4        // tests per memory round in render_kernel's marches (cfg3: 2 -> 14.0 ms, 3 -> 13.9, 4 -> 13.75, 6 -> 13.9)
 #endif
