@@ -52,8 +52,13 @@ __device__ constexpr float kInv255 = 0.003921568859368563f;
 // A measurement build only; the shipped library never defines it.
 #ifdef MRTX_PROF
 __device__ unsigned long long g_prof[16];
+#ifdef MRTX_PROF_FULLIV       // this measurement build uses the timers' slots for its own counts
+#define PROF_BEGIN(i)
+#define PROF_END(i)
+#else
 #define PROF_BEGIN(i) const unsigned long long _pt##i = __builtin_readcyclecounter()
 #define PROF_END(i) cnt[i] += (uint32_t)(__builtin_readcyclecounter() - _pt##i)
+#endif
 #else
 #define PROF_BEGIN(i)
 #define PROF_END(i)
@@ -299,6 +304,9 @@ constexpr int SEG_N = 16;
 struct Seg {
     float sa, ra, r1, r2, ca, c1, c2;
     int jlo, jhi;   // steps of this segment that can possibly be at/below the surface (see seg_setup)
+#ifdef MRTX_PROF_FULLIV
+    int why;        // measurement only: why the max-mip gave no interval (1 rows, 2 columns, 3 map edge; 0 = it did)
+#endif
     bool exact;
 };
 // per-march constants of r^2(s) = q0 + 2 b s + a s^2
@@ -359,6 +367,9 @@ __device__ __forceinline__ void seg_anchors(const FrameC& f, float oa, float ob,
         tap.usable = !sg.exact & (i1 - i0 <= 1) & (j1 - j0 <= (MRTX_WIDE_TAP ? MRTX_TAP_COLS - 1 : 1)) & (i0 >= -1) & (i1 <= f.mip_h) & (j0 >= -1) &
                      (j1 <= f.mip_w);
         tap.two_r = i1 > i0; tap.two_c = j1 > j0; tap.ncol = j1 - j0 + 1;
+#ifdef MRTX_PROF_FULLIV
+        sg.why = sg.exact ? 4 : (i1 - i0 > 1) ? 1 : (j1 - j0 > MRTX_TAP_COLS - 1) ? 2 : tap.usable ? 0 : 3;
+#endif
         // the mip is stored in row pairs as well (element (i, j) = (m[i][j], m[i+1][j])): one 16-byte load brings the
         // 2x2 cells at (i0, j0); the ones the footprint does not reach are ignored, so the bound is the old one
         tap.off = tap.usable ? ((uint32_t)((i0 + 1) * f.mip_pitch + j0 + 1) << 3) : 0u;
@@ -788,7 +799,9 @@ __device__ __forceinline__ void march_segment(const FrameC& f, MarchState& m, fl
     seg_setup<STATS>(f, oa, ob, oc, da, db, dc, m.rq, ka, m.rowA, m.colA, m.q2A, sg, rowB, colB, q2B, cnt);
 #ifdef MRTX_PROF_FULLIV   // measurement only: how many lanes get NO skip interval from the max-mip (footprint over more than 2 x 2 cells, or a true full interval)
     { const bool full = (sg.jlo == 1) & (sg.jhi == SEG_N) & !sg.exact;
-      cnt[13] += (uint32_t)__popcll(__ballot(full)); cnt[14] += (uint32_t)__popcll(__ballot(sg.exact)); }
+      cnt[13] += (uint32_t)__popcll(__ballot(full)); cnt[14] += (uint32_t)__popcll(__ballot(sg.exact));
+      cnt[5] += (uint32_t)__popcll(__ballot(full && sg.why == 1)); cnt[6] += (uint32_t)__popcll(__ballot(full && sg.why == 2));
+      cnt[7] += (uint32_t)__popcll(__ballot(full && sg.why == 3)); }
 #endif
     if (!PRIMARY) sg.jhi = max(min(sg.jhi, m.kend - ka), sg.jlo - 1);   // steps beyond kend cannot be at/below the surface
     // the medium max-mip cuts the interval once more (first_kept_step / last_kept_step above): camera rays from the front, shadow rays

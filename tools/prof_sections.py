@@ -40,13 +40,15 @@ names = ["trace total", "primary setup", "primary march", "bisect", "hit_vertex"
          "seg_setup (all marches)", "step loops (all marches)"]
 print(f"{wl} {sc}: kernel {st['kernel_ms']:.3f} ms, waves {v[10]}")
 for i, n in enumerate(names):
-    print(f"  {n:36s} {v[i]:16d} ticks  {v[i] / v[0]:.3f}")
+    print(f"  {n:36s} {v[i]:16d} ticks  {v[i] / max(1, v[0]):.3f}")
 print(f"  wave-level step iterations {v[11]} ({v[11] / max(1, v[10]):.1f} per wave), mean lanes evaluating {v[12] / max(1, v[11]):.1f}")
 print(f"  primary segments {v[15]} of which empty for the whole wave {v[13]}; shadow segments {v[8] - v[15]}, empty {v[14]}")
 if os.environ.get("TRIAL"):   # a -DMRTX_PROF -DMRTX_PROF_TRIAL build, PATH_SEG=2,4
     print(f"  TRIAL: step iterations {v[13]} ({v[13] / max(1, v[10]):.2f} per wave), mean lanes evaluating {v[14] / max(1, v[13]):.1f}; set-up + steps {v[15] / v[0]:.3f} of the trace")
 if os.environ.get("FULLIV"):   # a -DMRTX_PROF -DMRTX_PROF_FULLIV build
-    print(f"  FULLIV: lane-segments {v[9]}, of which without a skip interval from the max-mip {v[13]} ({v[13] / max(1, v[9]):.3f}), exact-fallback {v[14]} ({v[14] / max(1, v[9]):.4f})")
+    print(f"  FULLIV: lane-segments {v[9]}, of which without a skip interval from the max-mip {v[13]} ({v[13] / max(1, v[9]):.3f}), exact-fallback {v[14]} ({v[14] / max(1, v[9]):.4f}); "
+          f"of the former: footprint over more than two cell ROWS {v[5] / max(1, v[9]):.4f}, over more than the tap's COLUMNS {v[6] / max(1, v[9]):.4f}, map edge {v[7] / max(1, v[9]):.4f} "
+          f"(section timers 5-7 are overwritten in this build)")
 if os.environ.get("SPREAD"):
     print(f"  SPREAD: waves with a hit {v[9]}; lanes' texel spread at the hit <= 8: {v[13] / max(1, v[9]):.3f}, <= 16: {v[14] / max(1, v[9]):.3f}, <= 28: {v[15] / max(1, v[9]):.3f}")
 print(f"  wave-level segments {v[8]}, mean lanes alive in a segment {v[9] / max(1, v[8]):.1f}")
