@@ -57,3 +57,25 @@ def test_harness_passes_when_both_sides_see_the_same_bytes(monkeypatch):
     monkeypatch.setattr(common, "render_hip", hip_is_the_oracle)
     st = fuzz_cases.check_case(c)
     assert st["primary_hits"] == 2576
+
+
+def test_dense_flavour_leaves_the_ordinary_cases_alone():
+    """FUZZ_DENSE draws its terrain LAST from the generator's second stream: case k of a seed keeps its scene, camera, flags and
+    options whether or not the flavour is on (so a failing seed of an old campaign still means the same case), and with it most
+    cases get a terrain of >= 720 rows under a march step of at least 1.3e-2 radii."""
+    import itertools
+    import numpy as np
+    plain = list(itertools.islice(fuzz_cases.cases(5, dense=False), 12))
+    dense = list(itertools.islice(fuzz_cases.cases(5, dense=True), 12))
+    big = 0
+    for a, b in zip(plain, dense):
+        sa, sb = a[4], b[4]
+        assert (sa.width, sa.height, sa.spp_per_launch, sa.eye, sa.target, sa.vfov_deg, sa.light_pos) == \
+               (sb.width, sb.height, sb.spp_per_launch, sb.eye, sb.target, sb.vfov_deg, sb.light_pos)
+        assert a[5:8] == b[5:8] and a[8]["world"] == b[8]["world"] and a[8]["inwave"] == b[8]["inwave"]
+        if b[1].shape[0] >= 720:
+            big += 1
+            assert b[4].marching_step >= 1.3e-2 * b[4].radius / 10.0 * 0.999 and float(b[1].max()) == 1.0 and float(b[1].min()) > 0.9
+        else:
+            assert np.array_equal(a[1], b[1]) and sa.marching_step == sb.marching_step
+    assert big >= 5
